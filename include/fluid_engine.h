@@ -1,0 +1,283 @@
+/*
+ * fluid_engine.h — C ABI of the MI355X-native 3D Eulerian fluid-step engine.
+ *
+ * This is the drop-in boundary for ONE path of Matezzzz/vulkan-3d-fluid-simulation: the
+ * solver sections 00…14 (reference `shaders_fluid/00_init_particles … 14_particles`) as they are
+ * listed, ordered and wired in the reference's section lists:
+ *
+ *   SimulationInitializationSections   fluid_flow_sections.h:136-156   -> fluid_run_init()
+ *   SimulationStepSections (01a … 14)  fluid_flow_sections.h:159-338   -> fluid_run_step()
+ *   one Flow*Section of those lists                                    -> fluid_run_section()
+ *   FlowLoopPushConstantSection<…>(N, "12_solve_pressure")  :300-313   -> fluid_run_section_loop()
+ *   ImageAttachments / BufferAttachments enums              :10-16     -> fluid_image_id / fluid_buffer_id
+ *   SimulationParametersBufferData (264-byte std140 blob)   simulation_constants.h:153-174,
+ *       byte offsets shaders_fluid/fluids_uniform_buffer_layout.txt:4-56  -> fluid_params
+ *
+ * The reference has no FFI of its own: its "operator API" is the C++ section list driven by
+ * `complete()` once and `run(CommandBuffer&, FlowDescriptorContext&)` per frame (main.cpp:103-105,
+ * 111, 172).  Everything below is plain C: opaque context, plain pointers and sizes, integer status
+ * codes, no C++/torch types.  The C++ mirror of the reference classes (FlowSectionList & co.) sits on
+ * top of this header in fluid_flow_sections_amd.hpp; the Python binding (ctypes) in
+ * vulkan-3d-fluid-simulation_amd/engine.py.
+ *
+ * Conventions
+ *   - Grid W×H×D = params.fluid_size, cell index i=(x,y,z), linear x-fastest: idx = x + W*(y + H*z).
+ *   - Host-side layouts at upload/download are the reference image formats, densely packed:
+ *       VELOCITIES_1/2   RGBA32F  16 B/cell  (A unused; fluid_flow_sections.h:36-38)
+ *       CELL_TYPES / NEW_CELL_TYPES  R8_UINT  1 B/cell (:40-42)
+ *       PRESSURES_1/2, DIVERGENCES   R32F   4 B/cell (:44-47)
+ *       PARTICLE_DENSITIES_IMG       R32_UINT 4 B/cell (:49)
+ *       PARTICLES_BUF    vec4[particle_capacity], xyz + w = active flag (:72)
+ *   - Out-of-bounds image loads return 0, out-of-bounds stores/atomics are dropped (Vulkan
+ *     robust-image semantics the shaders rely on).
+ *   - All run_* calls enqueue asynchronously on the context's in-order HIP stream; stream order
+ *     replaces the reference's image barriers.  fluid_sync() is the fence.
+ *   - Every call returns 0 on success or a negative fluid_status; fluid_last_error() gives text.
+ *   - One host thread per context.
+ */
+#ifndef FLUID_ENGINE_H
+#define FLUID_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUID_ENGINE_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------- */
+typedef enum fluid_status {
+    FLUID_OK = 0,
+    FLUID_ERR_INVALID_ARG = -1,   /* null pointer, unknown id, bad enum                          */
+    FLUID_ERR_SIZE_MISMATCH = -2, /* host byte count does not match the attachment's size        */
+    FLUID_ERR_HIP = -3,           /* a HIP runtime call failed; text in fluid_last_error()       */
+    FLUID_ERR_NO_DEVICE = -4,     /* no usable gfx950 device                                     */
+    FLUID_ERR_UNSUPPORTED = -5,   /* valid request the engine does not implement (e.g. section   */
+                                  /* not meaningful on a Z-slab context)                         */
+    FLUID_ERR_OUT_OF_MEMORY = -6
+} fluid_status;
+
+/* ---- attachments: values are the reference enum values (fluid_flow_sections.h:10-16) -------- */
+typedef enum fluid_image_id {
+    FLUID_IMG_VELOCITIES_1 = 0,
+    FLUID_IMG_VELOCITIES_2 = 1,
+    FLUID_IMG_CELL_TYPES = 2,
+    FLUID_IMG_NEW_CELL_TYPES = 3,
+    FLUID_IMG_PRESSURES_1 = 4,
+    FLUID_IMG_PRESSURES_2 = 5,
+    FLUID_IMG_DIVERGENCES = 6,
+    FLUID_IMG_PARTICLE_DENSITIES_IMG = 7,
+    /* 8..11 = DETAILED_DENSITIES_IMG, DETAILED_DENSITIES_INERTIA_IMG, PARTICLE_DENSITIES_FLOAT_1/2:
+       surface-render inputs on the 5x grid, not on this path.  Using them
+       returns FLUID_ERR_UNSUPPORTED. */
+    FLUID_IMG_DETAILED_DENSITIES_IMG = 8,
+    FLUID_IMG_DETAILED_DENSITIES_INERTIA_IMG = 9,
+    FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1 = 10,
+    FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2 = 11,
+    FLUID_IMAGE_COUNT = 12
+} fluid_image_id;
+
+typedef enum fluid_buffer_id {
+    FLUID_BUF_PARTICLES_BUF = 0,
+    FLUID_BUF_MARCHING_CUBES_COUNTS_BUF = 1, /* render only: FLUID_ERR_UNSUPPORTED */
+    FLUID_BUF_MARCHING_CUBES_EDGES_BUF = 2,  /* render only: FLUID_ERR_UNSUPPORTED */
+    FLUID_BUF_SIMULATION_PARAMS_BUF = 3,
+    FLUID_BUFFER_COUNT = 4
+} fluid_buffer_id;
+
+/* ---- cell types (simulation_constants.h:144-146); the kernels read the values from params --- */
+enum { FLUID_CELL_INACTIVE = 0, FLUID_CELL_AIR = 1, FLUID_CELL_WATER = 2, FLUID_CELL_SOLID = 3 };
+
+/* ---- sections: one id per entry of the reference's section lists, named after the shader dir -- */
+typedef enum fluid_section_id {
+    /* SimulationInitializationSections, fluid_flow_sections.h:139-154 */
+    FLUID_SEC_INIT_CLEAR_VELOCITIES_1 = 0, /* :140 FlowClearColorSection(VELOCITIES_1, 0)          */
+    FLUID_SEC_INIT_CLEAR_CELL_TYPES = 1,   /* :141 FlowClearColorSection(CELL_TYPES, INACTIVE)     */
+    FLUID_SEC_00_INIT_PARTICLES = 2,       /* :143-153, init_particles.comp                        */
+    /* SimulationStepSections, fluid_flow_sections.h:163-338 */
+    FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES = 3,        /* :163                                     */
+    FLUID_SEC_01_UPDATE_DENSITIES = 4,                 /* :164-175 update_densities.comp           */
+    FLUID_SEC_02_UPDATE_WATER = 5,                     /* :176-187 update_water.comp               */
+    FLUID_SEC_03_UPDATE_AIR = 6,                       /* :188-198 update_active.comp              */
+    FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES = 7,  /* :199-211 extrapolated_velocities.comp    */
+    FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES = 8,      /* :212-225 extrapolate_velocities.comp     */
+    FLUID_SEC_06_UPDATE_CELL_TYPES = 9,                /* :226-236 update_cell_types.comp          */
+    FLUID_SEC_07_ADVECT = 10,                          /* :237-249 advect.comp                     */
+    FLUID_SEC_08_FORCES = 11,                          /* :250-261 forces.comp                     */
+    FLUID_SEC_09_DIFFUSE = 12,                         /* :262-274 diffuse.comp                    */
+    FLUID_SEC_10_SOLIDS = 13,                          /* :275-286 solids.comp                     */
+    FLUID_SEC_11_COMPUTE_DIVERGENCE = 14,              /* :287-297 compute_divergence.comp         */
+    FLUID_SEC_12A_CLEAR_PRESSURES_1 = 15,              /* :298                                     */
+    FLUID_SEC_12B_CLEAR_PRESSURES_2 = 16,              /* :299                                     */
+    FLUID_SEC_12_SOLVE_PRESSURE = 17,                  /* :300-313 pressure.comp (loop section)    */
+    FLUID_SEC_13_FIX_DIVERGENCE = 18,                  /* :314-326 fix_divergence.comp             */
+    FLUID_SEC_14_PARTICLES = 19,                       /* :327-338 particles.comp                  */
+    FLUID_SECTION_COUNT = 20
+} fluid_section_id;
+
+/* ---- parameters: byte-for-byte the reference's 264-byte std140 uniform block ----------------
+ * Offsets: shaders_fluid/fluids_uniform_buffer_layout.txt:4-56; write order
+ * simulation_constants.h:156-172.  Fields at 116-232 and 260 are render/surface-only and are
+ * carried but never read by this engine. */
+typedef struct fluid_params {
+    uint32_t fluid_size[3];                     /*   0 */
+    uint32_t fluid_volume;                      /*  12 */
+    uint32_t cell_type_inactive;                /*  16 */
+    uint32_t cell_type_air;                     /*  20 */
+    uint32_t cell_type_water;                   /*  24 */
+    uint32_t cell_type_solid;                   /*  28 */
+    float time_delta;                           /*  32 */
+    float pressure_air;                         /*  36 */
+    float cell_width;                           /*  40 */
+    float fluid_density;                        /*  44 */
+    uint32_t particle_compute_size[2];          /*  48 */
+    uint32_t _pad56[2];                         /*  56 */
+    uint32_t particle_spawn_cube_resolution[3]; /*  64 */
+    uint32_t particle_spawn_cube_volume;        /*  76 */
+    float particle_spawn_cube_offset[3];        /*  80 */
+    uint32_t _pad92;                            /*  92 */
+    float particle_spawn_cube_size[3];          /*  96 */
+    float gravity;                              /* 108 */
+    float diffuse_k;                            /* 112 */
+    int32_t detailed_resolution;                /* 116 */
+    int32_t detailed_resolution_volume;         /* 120 */
+    int32_t max_inertia;                        /* 124 */
+    int32_t inertia_increase_filled;            /* 128 */
+    int32_t required_neighbour_hits;            /* 132 */
+    int32_t inertia_increase_neighbour;         /* 136 */
+    int32_t inertia_decrease;                   /* 140 */
+    float dens_division_coefficient;            /* 144 */
+    float dens_diffuse_k;                       /* 148 */
+    uint32_t _pad152[2];                        /* 152 */
+    float particle_color[3];                    /* 160 */
+    float particle_base_size;                   /* 172 */
+    float light_dir[3];                         /* 176 */
+    uint32_t _pad188;                           /* 188 */
+    float ambient_color[3];                     /* 192 */
+    uint32_t _pad204;                           /* 204 */
+    float diffuse_color[3];                     /* 208 */
+    uint32_t _pad220;                           /* 220 */
+    uint32_t fluid_surface_render_size[3];      /* 224 */
+    float active_particle_w;                    /* 236 */
+    uint32_t fountain_position[3];              /* 240 */
+    float fountain_force;                       /* 252 */
+    float solid_repel_velocity;                 /* 256 */
+    float particle_max_size;                    /* 260 */
+} fluid_params;                                 /* 264 */
+
+#define FLUID_PARAMS_BYTES 264
+
+/* Fill `p` with the reference defaults (simulation_constants.h:7-139) for a grid of the given size:
+ * everything that the reference derives from fluid_size (fluid_volume, fountain_position :85,
+ * surface sizes) is recomputed; the particle spawn cube keeps the reference's 100^3 / (5,2,1.5) /
+ * (10,10,2) (:48-50) and particle_compute_size = (particle_capacity, 1) (:33,:162). Pure host code. */
+int fluid_params_default(fluid_params* p, uint32_t width, uint32_t height, uint32_t depth,
+                         uint32_t particle_capacity);
+
+/* ---- 09_diffuse behaviour ---------------------------------------------------- */
+typedef enum fluid_diffuse_mode {
+    FLUID_DIFFUSE_REFERENCE_EXACT = 0, /* diffuse.comp as written: the diffused value is shadowed,   */
+                                       /* VELOCITIES_1 = (VELOCITIES_2.xyz, 0)  (diffuse.comp:34-46) */
+    FLUID_DIFFUSE_INTENDED = 1         /* the 7-point explicit diffusion the shader means (:38-43)    */
+} fluid_diffuse_mode;
+
+/* ---- context -------------------------------------------------------------------------------- */
+typedef struct fluid_ctx fluid_ctx;
+
+typedef struct fluid_create_info {
+    uint32_t struct_bytes;       /* = sizeof(fluid_create_info), for ABI growth                      */
+    int32_t device;              /* HIP device ordinal; -1 = current device                         */
+    const void* params_blob;     /* 264 bytes, layout of fluid_params; fluid_size = GLOBAL grid      */
+    uint64_t particle_capacity;  /* PARTICLE_BUFFER_SIZE of the shaders (simulation_constants.h:29); */
+                                 /* 0 = particle_compute_size.x*.y from the blob                    */
+    uint32_t pressure_iterations;/* divergence_solve_iterations (simulation_constants.h:74) used by  */
+                                 /* fluid_run_step(); 0 = 200                                       */
+    /* Z-slab decomposition (one context per GPU). z_count = 0 means the whole grid.              */
+    uint32_t slab_z_begin;       /* first owned global z plane                                      */
+    uint32_t slab_z_count;       /* owned planes; the context also holds one ghost plane per side    */
+    void* hip_stream;            /* hipStream_t to enqueue on (borrowed); NULL = engine creates one  */
+    void* arena;                 /* optional caller-owned device memory for all attachments          */
+    uint64_t arena_bytes;        /*   (>= fluid_required_arena_bytes); NULL = engine hipMallocs      */
+} fluid_create_info;
+
+/* Device bytes a context with this geometry needs (pure host arithmetic). */
+uint64_t fluid_required_arena_bytes(const fluid_create_info* info);
+
+/* Replaces: SimulationDescriptors ctor (fluid_flow_sections.h:26-96) + params upload (:86). */
+int fluid_create(fluid_ctx** out, const fluid_create_info* info);
+void fluid_destroy(fluid_ctx* ctx);
+
+/* Text of the last error on this context (or of the last failed fluid_create when ctx == NULL). */
+const char* fluid_last_error(const fluid_ctx* ctx);
+
+int fluid_abi_version(void);
+
+/* ---- data movement (the reference never reads back; these exist for tests, checkpoints and the
+ *      caller that replaces the renderer).  Synchronous with respect to the context's stream.   */
+int fluid_upload_image(fluid_ctx* ctx, int image_id, const void* host, uint64_t bytes);
+int fluid_download_image(fluid_ctx* ctx, int image_id, void* host, uint64_t bytes);
+int fluid_upload_buffer(fluid_ctx* ctx, int buffer_id, const void* host, uint64_t bytes);
+int fluid_download_buffer(fluid_ctx* ctx, int buffer_id, void* host, uint64_t bytes);
+/* Bytes of the owned (non-ghost) part of an attachment as seen by upload/download. */
+int fluid_image_bytes(const fluid_ctx* ctx, int image_id, uint64_t* bytes);
+int fluid_buffer_bytes(const fluid_ctx* ctx, int buffer_id, uint64_t* bytes);
+
+/* Replace the params blob (re-reads every hot-path field; fluid_size must not change). */
+int fluid_set_params(fluid_ctx* ctx, const void* params_blob);
+int fluid_set_pressure_iterations(fluid_ctx* ctx, uint32_t iterations);
+int fluid_set_diffuse_mode(fluid_ctx* ctx, int mode);
+
+/* ---- section dispatch ----------------------------------------------------------------------- */
+/* One entry of a section list.  For FLUID_SEC_12_SOLVE_PRESSURE this is ONE dispatch with the push
+ * constant taken from the context's loop counter (first dispatch after 12A/12B: is_even_iteration
+ * = 1, then alternating) — use fluid_run_section_loop or fluid_run_pressure_dispatch for explicit
+ * control. */
+int fluid_run_section(fluid_ctx* ctx, int section_id);
+
+/* FlowLoopPushConstantSection<FlowComputePushConstantSection>(iterations, …) of
+ * fluid_flow_sections.h:300-313: `iterations` dispatches, dispatch k has is_even_iteration =
+ * (k % 2 == 0), i.e. reads PRESSURES_1 / writes PRESSURES_2 on even k (pressure.comp:28-31,71-75;
+ * SURVEY.md F2).  Only FLUID_SEC_12_SOLVE_PRESSURE is a loop section on this path. */
+int fluid_run_section_loop(fluid_ctx* ctx, int section_id, uint32_t iterations);
+
+/* One 12_solve_pressure dispatch with an explicit push constant (pressure.comp:29-31). */
+int fluid_run_pressure_dispatch(fluid_ctx* ctx, uint32_t is_even_iteration);
+
+/* SimulationInitializationSections::run (fluid_flow_sections.h:139-154; main.cpp:111). */
+int fluid_run_init(fluid_ctx* ctx);
+/* SimulationStepSections::run restricted to 01a…14 (fluid_flow_sections.h:163-338; main.cpp:172). */
+int fluid_run_step(fluid_ctx* ctx);
+
+/* Fence: wait until everything enqueued so far has executed (replaces fence wait main.cpp:124). */
+int fluid_sync(fluid_ctx* ctx);
+
+/* ---- timing --------------------------------------------------------------------------------- */
+/* When enabled, every run_section / loop records HIP events on the context's stream.           */
+int fluid_enable_timing(fluid_ctx* ctx, int enabled);
+/* Accumulated device milliseconds and launch count of a section since the last reset.          */
+int fluid_section_time_ms(fluid_ctx* ctx, int section_id, double* total_ms, uint64_t* calls);
+int fluid_reset_timing(fluid_ctx* ctx);
+
+/* ---- multi-GPU plumbing (Z-slab contexts) ------------------------------------------------------
+ * Device address and byte count of one XY plane of an image, for halo exchange by the caller's
+ * communicator (RCCL Send/Recv).  `plane` is a LOCAL z index: -1 = lower ghost plane,
+ * 0 … z_count-1 = owned planes, z_count = upper ghost plane.  Planes are contiguous in memory.    */
+int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** device_ptr,
+                          uint64_t* bytes);
+/* Geometry of this context. */
+int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* slab_z_begin,
+                       uint32_t* slab_z_count, uint64_t* particle_capacity);
+
+/* ---- engine options (performance variants of the same arithmetic; results are bit-identical) -- */
+typedef enum fluid_option {
+    FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto, 1 = plain one-cell-per-thread, 2 = z-marching tile   */
+    FLUID_OPT_COUNT
+} fluid_option;
+int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUID_ENGINE_H */

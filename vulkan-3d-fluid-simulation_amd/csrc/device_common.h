@@ -1,0 +1,65 @@
+// device_common.h — shared device-side definitions for the gfx950 fluid-step kernels.
+//
+// Memory model of one context (one GPU, one Z-slab of the global grid):
+//   every grid image holds (Dl + 2) XY planes, x fastest: one ghost plane below local z = -1, the Dl
+//   owned planes, one ghost plane above.  Kernel pointers address owned plane 0, so local z in
+//   [-1, Dl] is always a valid load.  Ghost planes at a domain face stay zero for the lifetime of
+//   the context, which IS the reference's out-of-bounds image semantics in z ("load returns 0",
+//   SURVEY.md F4); ghost planes between two slabs are filled by the caller's halo exchange.
+//   x and y out-of-bounds are tested in the kernels.
+//
+// Arithmetic contract: fp32, one rounding per GLSL operation, in source order; this translation
+// unit is compiled with -ffp-contract=off and IEEE division (hipcc default) so results are
+// bit-identical to the CPU oracle (oracle/fluid_oracle.c), which is compiled the same way.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fluid {
+
+struct GridK {
+    int W, H, Dl;   // local extents (Dl = owned planes)
+    int Dg;         // global depth
+    int z0;         // global z of local plane 0
+    int64_t plane;  // W*H cells
+};
+
+// Hot-path fields of the 264-byte params block (include/fluid_engine.h: fluid_params), passed by
+// value to every kernel instead of a uniform buffer.
+struct ParamsK {
+    uint32_t t_inactive, t_air, t_water, t_solid;  // blob offsets 16..28
+    float dt, p_air, dx, rho;                      // 32..44
+    uint32_t spawn_res[3];                         // 64
+    uint32_t spawn_volume;                         // 76
+    float spawn_offset[3];                         // 80
+    float spawn_size[3];                           // 96
+    float gravity;                                 // 108
+    float diffuse_k;                               // 112
+    float active_w;                                // 236
+    uint32_t fountain[3];                          // 240
+    float fountain_force;                          // 252
+    float repel;                                   // 256
+};
+
+__device__ __forceinline__ int64_t cidx(const GridK& g, int x, int y, int lz) {
+    return (int64_t)x + (int64_t)g.W * ((int64_t)y + (int64_t)g.H * (int64_t)lz);
+}
+__device__ __forceinline__ bool xy_in(const GridK& g, int x, int y) {
+    return (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
+}
+// imageLoad with robust OOB semantics; lz must be in [-1, Dl].
+__device__ __forceinline__ uint32_t type_at(const uint8_t* __restrict__ t, const GridK& g, int x,
+                                            int y, int lz) {
+    return xy_in(g, x, y) ? (uint32_t)t[cidx(g, x, y, lz)] : 0u;
+}
+__device__ __forceinline__ float f32_at(const float* __restrict__ a, const GridK& g, int x, int y,
+                                        int lz) {
+    return xy_in(g, x, y) ? a[cidx(g, x, y, lz)] : 0.0f;
+}
+__device__ __forceinline__ float4 vel_at(const float4* __restrict__ v, const GridK& g, int x, int y,
+                                         int lz) {
+    return xy_in(g, x, y) ? v[cidx(g, x, y, lz)] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace fluid

@@ -1,0 +1,928 @@
+// engine.hip — host side of the C ABI in include/fluid_engine.h: context, device memory, the
+// section table (the reference's SimulationInitializationSections / SimulationStepSections,
+// /root/reference/fluid_flow_sections.h:136-338) and kernel launches on one in-order HIP stream.
+//
+// gfx950 only.  There is no CPU path in this library: every section either launches a HIP kernel
+// or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fluid_engine.h"
+#include "device_common.h"
+#include "kernels_grid.h"
+#include "kernels_pressure.h"
+#include "kernels_sampler.h"
+
+static_assert(sizeof(fluid_params) == FLUID_PARAMS_BYTES, "params block must be 264 bytes");
+static_assert(offsetof(fluid_params, particle_compute_size) == 48, "std140 offset");
+static_assert(offsetof(fluid_params, particle_spawn_cube_resolution) == 64, "std140 offset");
+static_assert(offsetof(fluid_params, particle_spawn_cube_offset) == 80, "std140 offset");
+static_assert(offsetof(fluid_params, particle_spawn_cube_size) == 96, "std140 offset");
+static_assert(offsetof(fluid_params, gravity) == 108, "std140 offset");
+static_assert(offsetof(fluid_params, dens_diffuse_k) == 148, "std140 offset");
+static_assert(offsetof(fluid_params, particle_color) == 160, "std140 offset");
+static_assert(offsetof(fluid_params, light_dir) == 176, "std140 offset");
+static_assert(offsetof(fluid_params, ambient_color) == 192, "std140 offset");
+static_assert(offsetof(fluid_params, diffuse_color) == 208, "std140 offset");
+static_assert(offsetof(fluid_params, fluid_surface_render_size) == 224, "std140 offset");
+static_assert(offsetof(fluid_params, active_particle_w) == 236, "std140 offset");
+static_assert(offsetof(fluid_params, fountain_position) == 240, "std140 offset");
+static_assert(offsetof(fluid_params, solid_repel_velocity) == 256, "std140 offset");
+
+using namespace fluid;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint64_t kAlign = 4096;
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct ImageDesc {
+    uint32_t elem_bytes = 0;   // bytes per cell
+    uint64_t offset = 0;       // arena offset of ghost plane -1
+    uint64_t bytes = 0;        // (Dl + 2) planes
+};
+
+struct TimerSlot {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int section = -1;
+};
+
+}  // namespace
+
+struct fluid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t* arena = nullptr;
+    bool own_arena = false;
+    uint64_t arena_bytes = 0;
+
+    fluid_params params{};
+    ParamsK pk{};
+    GridK g{};
+    uint64_t particle_capacity = 0;
+    uint64_t particles_offset = 0;
+    uint32_t pressure_iterations = 200;
+    int diffuse_mode = FLUID_DIFFUSE_REFERENCE_EXACT;
+    uint32_t pressure_dispatch_index = 0;  // loop counter of the 12_solve_pressure section
+    bool is_slab = false;
+
+    ImageDesc img[8];
+    int64_t opt[FLUID_OPT_COUNT] = {0};
+
+    bool timing = false;
+    std::vector<TimerSlot> pending;
+    std::vector<TimerSlot> free_slots;
+    double sec_ms[FLUID_SECTION_COUNT] = {0};
+    uint64_t sec_calls[FLUID_SECTION_COUNT] = {0};
+
+    std::string error;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+    template <typename T>
+    T* plane0(int image) const {  // owned plane 0
+        return reinterpret_cast<T*>(arena + img[image].offset +
+                                    (uint64_t)g.plane * img[image].elem_bytes);
+    }
+    float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
+    uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
+};
+
+#define HIP_TRY(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return (ctx)->fail(FLUID_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+const uint32_t kElemBytes[8] = {16, 16, 1, 1, 4, 4, 4, 4};
+
+int validate_params(const fluid_params& p, std::string& err) {
+    char buf[256];
+    if (p.fluid_size[0] == 0 || p.fluid_size[1] == 0 || p.fluid_size[2] == 0) {
+        err = "fluid_size must be non-zero in every dimension";
+        return FLUID_ERR_INVALID_ARG;
+    }
+    if ((uint64_t)p.fluid_size[0] * p.fluid_size[1] * p.fluid_size[2] > 0xFFFFFFFFull) {
+        err = "fluid_size volume must fit in 32 bits (fluid_volume is a uint)";
+        return FLUID_ERR_INVALID_ARG;
+    }
+    const uint32_t t[4] = {p.cell_type_inactive, p.cell_type_air, p.cell_type_water,
+                           p.cell_type_solid};
+    for (int i = 0; i < 4; i++) {
+        if (t[i] > 255u) {
+            err = "cell type values must fit the R8_UINT cell type image";
+            return FLUID_ERR_INVALID_ARG;
+        }
+        for (int j = 0; j < i; j++)
+            if (t[i] == t[j]) {
+                snprintf(buf, sizeof buf, "cell type values must be distinct (%u used twice)", t[i]);
+                err = buf;
+                return FLUID_ERR_INVALID_ARG;
+            }
+    }
+    if (p.particle_spawn_cube_resolution[0] == 0 || p.particle_spawn_cube_resolution[1] == 0 ||
+        p.particle_spawn_cube_resolution[2] == 0) {
+        err = "particle_spawn_cube_resolution must be non-zero";
+        return FLUID_ERR_INVALID_ARG;
+    }
+    return FLUID_OK;
+}
+
+ParamsK make_params_k(const fluid_params& p) {
+    ParamsK k{};
+    k.t_inactive = p.cell_type_inactive;
+    k.t_air = p.cell_type_air;
+    k.t_water = p.cell_type_water;
+    k.t_solid = p.cell_type_solid;
+    k.dt = p.time_delta;
+    k.p_air = p.pressure_air;
+    k.dx = p.cell_width;
+    k.rho = p.fluid_density;
+    for (int i = 0; i < 3; i++) {
+        k.spawn_res[i] = p.particle_spawn_cube_resolution[i];
+        k.spawn_offset[i] = p.particle_spawn_cube_offset[i];
+        k.spawn_size[i] = p.particle_spawn_cube_size[i];
+        k.fountain[i] = p.fountain_position[i];
+    }
+    k.spawn_volume = p.particle_spawn_cube_volume;
+    k.gravity = p.gravity;
+    k.diffuse_k = p.diffuse_k;
+    k.active_w = p.active_particle_w;
+    k.fountain_force = p.fountain_force;
+    k.repel = p.solid_repel_velocity;
+    return k;
+}
+
+struct Layout {
+    uint64_t img_offset[8], img_bytes[8];
+    uint64_t particles_offset, particles_bytes;
+    uint64_t total;
+};
+
+int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout& L,
+                   uint64_t& capacity, uint32_t& z0, uint32_t& dl) {
+    z0 = 0;
+    dl = p.fluid_size[2];
+    if (info->slab_z_count != 0) {
+        z0 = info->slab_z_begin;
+        dl = info->slab_z_count;
+        if ((uint64_t)z0 + dl > p.fluid_size[2]) return FLUID_ERR_INVALID_ARG;
+    }
+    capacity = info->particle_capacity;
+    if (capacity == 0)
+        capacity = (uint64_t)p.particle_compute_size[0] * (uint64_t)p.particle_compute_size[1];
+    const uint64_t plane = (uint64_t)p.fluid_size[0] * p.fluid_size[1];
+    uint64_t off = 0;
+    for (int i = 0; i < 8; i++) {
+        L.img_offset[i] = off;
+        L.img_bytes[i] = plane * (uint64_t)(dl + 2) * kElemBytes[i];
+        off = align_up(off + L.img_bytes[i], kAlign);
+    }
+    L.particles_offset = off;
+    L.particles_bytes = capacity * 16;
+    off = align_up(off + L.particles_bytes, kAlign);
+    L.total = std::max<uint64_t>(off, kAlign);
+    return FLUID_OK;
+}
+
+dim3 cell_block() { return dim3(64, 4, 1); }
+dim3 cell_grid(const GridK& g) { return dim3((g.W + 63) / 64, (g.H + 3) / 4, g.Dl); }
+
+// ---- timing ----------------------------------------------------------------------------------
+int fold_timers(fluid_ctx* c) {
+    if (c->pending.empty()) return FLUID_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& s : c->pending) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, s.start, s.stop));
+        c->sec_ms[s.section] += ms;
+        c->sec_calls[s.section] += 1;
+        c->free_slots.push_back(s);
+    }
+    c->pending.clear();
+    return FLUID_OK;
+}
+
+struct SectionTimer {
+    fluid_ctx* c;
+    TimerSlot slot;
+    bool active = false;
+    int begin(int section) {
+        if (!c->timing) return FLUID_OK;
+        if (c->pending.size() >= 8192) {
+            int rc = fold_timers(c);
+            if (rc) return rc;
+        }
+        if (!c->free_slots.empty()) {
+            slot = c->free_slots.back();
+            c->free_slots.pop_back();
+        } else {
+            HIP_TRY(c, hipEventCreate(&slot.start));
+            HIP_TRY(c, hipEventCreate(&slot.stop));
+        }
+        slot.section = section;
+        HIP_TRY(c, hipEventRecord(slot.start, c->stream));
+        active = true;
+        return FLUID_OK;
+    }
+    int end() {
+        if (!active) return FLUID_OK;
+        HIP_TRY(c, hipEventRecord(slot.stop, c->stream));
+        c->pending.push_back(slot);
+        active = false;
+        return FLUID_OK;
+    }
+};
+
+// ---- fills -------------------------------------------------------------------------------------
+// Fill the OWNED planes of an image with a repeated 32-bit (or 8-bit) pattern.
+int fill_image(fluid_ctx* c, int image, uint32_t pattern32) {
+    const uint64_t bytes = c->owned_cells() * c->img[image].elem_bytes;
+    uint8_t* dst = c->plane0<uint8_t>(image);
+    // plane0 is 16-byte aligned when plane*elem is; W*H*elem may not be a multiple of 16 for tiny
+    // odd grids, so split into an aligned vector body and byte tails.
+    const uint64_t addr = reinterpret_cast<uint64_t>(dst);
+    const uint64_t head = std::min<uint64_t>(bytes, (16 - (addr & 15)) & 15);
+    const uint64_t body = (bytes - head) / 16;
+    const uint64_t tail_begin = head + body * 16;
+    if (c->img[image].elem_bytes == 1) pattern32 = (pattern32 & 0xFFu) * 0x01010101u;
+    if (head % c->img[image].elem_bytes != 0)
+        return c->fail(FLUID_ERR_UNSUPPORTED, "image base not element-aligned");
+    if (body > 0) {
+        const int blocks = (int)std::min<uint64_t>((body + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(k_fill_u32x4, dim3(blocks), dim3(256), 0, c->stream,
+                           reinterpret_cast<uint4*>(dst + head), (int64_t)body,
+                           make_uint4(pattern32, pattern32, pattern32, pattern32));
+    }
+    // head/tail (< 16 bytes each): memsets of the pattern
+    auto small = [&](uint64_t b, uint64_t e) -> int {
+        if (e <= b) return FLUID_OK;
+        if (c->img[image].elem_bytes == 1) {
+            HIP_TRY(c, hipMemsetAsync(dst + b, (int)(pattern32 & 0xFF), e - b, c->stream));
+        } else {
+            HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst + b), (int)pattern32,
+                                         (e - b) / 4, c->stream));
+        }
+        return FLUID_OK;
+    };
+    int rc = small(0, head);
+    if (rc) return rc;
+    rc = small(tail_begin, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+uint32_t f32_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+// ---- 12_solve_pressure dispatch ---------------------------------------------------------------
+int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
+    const GridK& g = c->g;
+    // pressure.comp:71-75
+    const float* pin = c->plane0<float>(is_even_iteration == 1 ? FLUID_IMG_PRESSURES_1
+                                                               : FLUID_IMG_PRESSURES_2);
+    float* pout = c->plane0<float>(is_even_iteration == 1 ? FLUID_IMG_PRESSURES_2
+                                                          : FLUID_IMG_PRESSURES_1);
+    const uint8_t* t = c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES);
+    const float* div = c->plane0<float>(FLUID_IMG_DIVERGENCES);
+    int64_t variant = c->opt[FLUID_OPT_PRESSURE_KERNEL];
+    const bool zmarch_ok = (g.W % 4 == 0);
+    if (variant == 0) variant = (zmarch_ok && g.W >= 64) ? 2 : 1;
+    if (variant >= 2 && !zmarch_ok) variant = 1;
+    if (variant == 1) {
+        hipLaunchKernelGGL(k12_plain, cell_grid(g), cell_block(), 0, c->stream, t, div, pin, pout, g,
+                           c->pk);
+    } else {
+        // pick the z chunk so the launch has a few thousand workgroups (>> 256 CUs)
+        const int ry = variant == 3 ? 4 : (variant == 4 ? 1 : 2);
+        const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
+        int zchunk = g.Dl;
+        while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048) zchunk /= 2;
+        const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
+        if (ry == 4)
+            hipLaunchKernelGGL(k12_zmarch<4>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
+                               c->pk, zchunk);
+        else if (ry == 1)
+            hipLaunchKernelGGL(k12_zmarch<1>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
+                               c->pk, zchunk);
+        else
+            hipLaunchKernelGGL(k12_zmarch<2>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
+                               c->pk, zchunk);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+int slab_unsupported(fluid_ctx* c, const char* what) {
+    return c->fail(FLUID_ERR_UNSUPPORTED,
+                   "%s is not available on a Z-slab context yet (needs particle ownership / "
+                   "wide velocity halos)",
+                   what);
+}
+
+// ---- one section --------------------------------------------------------------------------------
+int run_section_impl(fluid_ctx* c, int section) {
+    const GridK& g = c->g;
+    const ParamsK& pk = c->pk;
+    const dim3 grid = cell_grid(g), block = cell_block();
+    uint8_t* T = c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES);
+    uint8_t* newT = c->plane0<uint8_t>(FLUID_IMG_NEW_CELL_TYPES);
+    float4* V1 = c->plane0<float4>(FLUID_IMG_VELOCITIES_1);
+    float4* V2 = c->plane0<float4>(FLUID_IMG_VELOCITIES_2);
+    uint32_t* dens = c->plane0<uint32_t>(FLUID_IMG_PARTICLE_DENSITIES_IMG);
+    const unsigned pblocks = (unsigned)((c->particle_capacity + 255) / 256);
+
+    switch (section) {
+        case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
+            return fill_image(c, FLUID_IMG_VELOCITIES_1, 0u);
+        case FLUID_SEC_INIT_CLEAR_CELL_TYPES:
+            return fill_image(c, FLUID_IMG_CELL_TYPES, pk.t_inactive);
+        case FLUID_SEC_00_INIT_PARTICLES:
+            if (c->particle_capacity == 0) return FLUID_OK;
+            hipLaunchKernelGGL(k00_init_particles, dim3(pblocks), dim3(256), 0, c->stream,
+                               c->particles(), c->particle_capacity, pk);
+            break;
+        case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES:
+            return fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
+        case FLUID_SEC_01_UPDATE_DENSITIES: {
+            if (c->particle_capacity == 0) return FLUID_OK;
+            const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
+            const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
+            hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                               c->particles(), c->particle_capacity, dens, g, pk);
+            break;
+        }
+        case FLUID_SEC_02_UPDATE_WATER:
+            hipLaunchKernelGGL(k02_update_water, grid, block, 0, c->stream, dens, newT, g, pk);
+            break;
+        case FLUID_SEC_03_UPDATE_AIR:
+            hipLaunchKernelGGL(k03_update_air, grid, block, 0, c->stream, newT, g, pk);
+            break;
+        case FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES:
+            hipLaunchKernelGGL(k04_extrapolated, grid, block, 0, c->stream, T, V1, V2, g, pk);
+            break;
+        case FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES:
+            hipLaunchKernelGGL(k05_set_extrapolated, grid, block, 0, c->stream, newT, T, V2, V1, g,
+                               pk);
+            break;
+        case FLUID_SEC_06_UPDATE_CELL_TYPES:
+            HIP_TRY(c, hipMemcpyAsync(T, newT, c->owned_cells(), hipMemcpyDeviceToDevice,
+                                      c->stream));
+            return FLUID_OK;
+        case FLUID_SEC_07_ADVECT:
+            if (c->is_slab) return slab_unsupported(c, "07_advect");
+            hipLaunchKernelGGL(k07_advect, grid, block, 0, c->stream, T, V1, V2, g, pk);
+            break;
+        case FLUID_SEC_08_FORCES:
+            hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
+            break;
+        case FLUID_SEC_09_DIFFUSE:
+            if (c->diffuse_mode == FLUID_DIFFUSE_INTENDED)
+                hipLaunchKernelGGL(k09_diffuse<true>, grid, block, 0, c->stream, T, V2, V1, g, pk);
+            else
+                hipLaunchKernelGGL(k09_diffuse<false>, grid, block, 0, c->stream, T, V2, V1, g, pk);
+            break;
+        case FLUID_SEC_10_SOLIDS:
+            hipLaunchKernelGGL(k10_solids, grid, block, 0, c->stream, T, V1, g, pk);
+            break;
+        case FLUID_SEC_11_COMPUTE_DIVERGENCE:
+            hipLaunchKernelGGL(k11_divergence, grid, block, 0, c->stream, V1,
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g);
+            break;
+        case FLUID_SEC_12A_CLEAR_PRESSURES_1:
+            c->pressure_dispatch_index = 0;
+            return fill_image(c, FLUID_IMG_PRESSURES_1, f32_bits(pk.p_air));
+        case FLUID_SEC_12B_CLEAR_PRESSURES_2:
+            c->pressure_dispatch_index = 0;
+            return fill_image(c, FLUID_IMG_PRESSURES_2, f32_bits(pk.p_air));
+        case FLUID_SEC_12_SOLVE_PRESSURE: {
+            const uint32_t even = (c->pressure_dispatch_index % 2u) == 0u ? 1u : 0u;
+            c->pressure_dispatch_index++;
+            return launch_pressure(c, even);
+        }
+        case FLUID_SEC_13_FIX_DIVERGENCE:
+            hipLaunchKernelGGL(k13_fix_divergence, grid, block, 0, c->stream, T,
+                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk);
+            break;
+        case FLUID_SEC_14_PARTICLES:
+            if (c->is_slab) return slab_unsupported(c, "14_particles");
+            if (c->particle_capacity == 0) return FLUID_OK;
+            hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
+                               c->particles(), c->particle_capacity, g, pk);
+            break;
+        default:
+            return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+int timed_section(fluid_ctx* c, int section) {
+    if (section < 0 || section >= FLUID_SECTION_COUNT)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section);
+    SectionTimer tm{c};
+    int rc = tm.begin(section);
+    if (rc) return rc;
+    rc = run_section_impl(c, section);
+    int rc2 = tm.end();
+    return rc ? rc : rc2;
+}
+
+int check_image(fluid_ctx* c, int image_id) {
+    if (image_id < 0 || image_id >= FLUID_IMAGE_COUNT)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown image id %d", image_id);
+    if (image_id >= 8)
+        return c->fail(FLUID_ERR_UNSUPPORTED,
+                       "image %d belongs to the surface-render path (sections 15-18), which this "
+                       "engine does not implement",
+                       image_id);
+    return FLUID_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int fluid_abi_version(void) { return FLUID_ENGINE_ABI_VERSION; }
+
+int fluid_params_default(fluid_params* p, uint32_t w, uint32_t h, uint32_t d, uint32_t capacity) {
+    if (!p) return FLUID_ERR_INVALID_ARG;
+    memset(p, 0, sizeof *p);
+    // simulation_constants.h:7-139
+    p->fluid_size[0] = w;
+    p->fluid_size[1] = h;
+    p->fluid_size[2] = d;
+    p->fluid_volume = (uint32_t)((uint64_t)w * h * d);
+    p->cell_type_inactive = FLUID_CELL_INACTIVE;
+    p->cell_type_air = FLUID_CELL_AIR;
+    p->cell_type_water = FLUID_CELL_WATER;
+    p->cell_type_solid = FLUID_CELL_SOLID;
+    p->time_delta = 0.01f;
+    p->pressure_air = 1.0f;
+    p->cell_width = 1.0f;
+    p->fluid_density = 1.0f;
+    p->particle_compute_size[0] = capacity;
+    p->particle_compute_size[1] = 1;
+    p->particle_spawn_cube_resolution[0] = 100;
+    p->particle_spawn_cube_resolution[1] = 100;
+    p->particle_spawn_cube_resolution[2] = 100;
+    p->particle_spawn_cube_volume = 100u * 100u * 100u;
+    p->particle_spawn_cube_offset[0] = 5.0f;
+    p->particle_spawn_cube_offset[1] = 2.0f;
+    p->particle_spawn_cube_offset[2] = 1.5f;
+    p->particle_spawn_cube_size[0] = 10.0f;
+    p->particle_spawn_cube_size[1] = 10.0f;
+    p->particle_spawn_cube_size[2] = 2.0f;
+    p->gravity = 10.0f;
+    p->diffuse_k = 0.01f;
+    p->detailed_resolution = 5;
+    p->detailed_resolution_volume = (int32_t)((125ull * w * h * d) & 0x7FFFFFFFull);
+    p->max_inertia = 100;
+    p->inertia_increase_filled = 4;
+    p->required_neighbour_hits = 1;
+    p->inertia_increase_neighbour = 1;
+    p->inertia_decrease = 1;
+    p->dens_division_coefficient = 30.0f;
+    p->dens_diffuse_k = 0.1f;
+    p->particle_color[0] = 1.0f;
+    p->particle_base_size = 10.0f;
+    p->light_dir[0] = 1.0f;
+    p->light_dir[1] = -3.0f;
+    p->light_dir[2] = 1.0f;
+    p->ambient_color[2] = 0.3f;
+    p->diffuse_color[1] = 0.8f;
+    p->diffuse_color[2] = 0.7f;
+    p->fluid_surface_render_size[0] = 5 * w - 1;
+    p->fluid_surface_render_size[1] = 5 * h - 1;
+    p->fluid_surface_render_size[2] = 5 * d - 1;
+    p->active_particle_w = 1.0f;
+    p->fountain_position[0] = w / 2;
+    p->fountain_position[1] = h - 2;
+    p->fountain_position[2] = d / 2;
+    p->fountain_force = -3000.0f;
+    p->solid_repel_velocity = 0.01f;
+    p->particle_max_size = 20.0f;
+    return FLUID_OK;
+}
+
+uint64_t fluid_required_arena_bytes(const fluid_create_info* info) {
+    if (!info || !info->params_blob) return 0;
+    fluid_params p;
+    memcpy(&p, info->params_blob, sizeof p);
+    std::string err;
+    if (validate_params(p, err)) return 0;
+    Layout L;
+    uint64_t cap;
+    uint32_t z0, dl;
+    if (compute_layout(info, p, L, cap, z0, dl)) return 0;
+    return L.total;
+}
+
+int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
+    if (!out || !info || !info->params_blob || info->struct_bytes < sizeof(fluid_create_info)) {
+        g_create_error = "fluid_create: null argument or struct_bytes too small";
+        return FLUID_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    fluid_params p;
+    memcpy(&p, info->params_blob, sizeof p);
+    int rc = validate_params(p, g_create_error);
+    if (rc) return rc;
+    Layout L;
+    uint64_t capacity;
+    uint32_t z0, dl;
+    rc = compute_layout(info, p, L, capacity, z0, dl);
+    if (rc) {
+        g_create_error = "slab_z_begin + slab_z_count exceeds fluid_size.z";
+        return rc;
+    }
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        return FLUID_ERR_NO_DEVICE;
+    }
+    int dev = info->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) {
+        g_create_error = "device ordinal out of range";
+        return FLUID_ERR_INVALID_ARG;
+    }
+    if ((e = hipSetDevice(dev)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return FLUID_ERR_HIP;
+    }
+
+    fluid_ctx* c = new fluid_ctx();
+    c->device = dev;
+    c->params = p;
+    c->pk = make_params_k(p);
+    c->g.W = (int)p.fluid_size[0];
+    c->g.H = (int)p.fluid_size[1];
+    c->g.Dg = (int)p.fluid_size[2];
+    c->g.Dl = (int)dl;
+    c->g.z0 = (int)z0;
+    c->g.plane = (int64_t)p.fluid_size[0] * p.fluid_size[1];
+    c->is_slab = dl != p.fluid_size[2];
+    c->particle_capacity = capacity;
+    c->pressure_iterations = info->pressure_iterations ? info->pressure_iterations : 200;
+    for (int i = 0; i < 8; i++) {
+        c->img[i].elem_bytes = kElemBytes[i];
+        c->img[i].offset = L.img_offset[i];
+        c->img[i].bytes = L.img_bytes[i];
+    }
+    c->particles_offset = L.particles_offset;
+    c->arena_bytes = L.total;
+
+    auto bail = [&](int code, const std::string& msg) {
+        g_create_error = msg;
+        fluid_destroy(c);
+        return code;
+    };
+    if (info->hip_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(info->hip_stream);
+    } else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail(FLUID_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        c->own_stream = true;
+    }
+    if (info->arena) {
+        if (info->arena_bytes < L.total) return bail(FLUID_ERR_SIZE_MISMATCH, "arena too small");
+        if (reinterpret_cast<uint64_t>(info->arena) % 256 != 0)
+            return bail(FLUID_ERR_INVALID_ARG, "arena must be 256-byte aligned");
+        c->arena = static_cast<uint8_t*>(info->arena);
+    } else {
+        void* ptr = nullptr;
+        if ((e = hipMalloc(&ptr, L.total)) != hipSuccess)
+            return bail(FLUID_ERR_OUT_OF_MEMORY, std::string("hipMalloc of ") +
+                                                     std::to_string(L.total) +
+                                                     " bytes: " + hipGetErrorString(e));
+        c->arena = static_cast<uint8_t*>(ptr);
+        c->own_arena = true;
+    }
+    // zero everything once: the ghost planes at the domain faces must read as 0 forever
+    if ((e = hipMemsetAsync(c->arena, 0, L.total, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return bail(FLUID_ERR_HIP, std::string("arena clear: ") + hipGetErrorString(e));
+    *out = c;
+    return FLUID_OK;
+}
+
+void fluid_destroy(fluid_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->pending) c->free_slots.push_back(s);
+    for (auto& s : c->free_slots) {
+        if (s.start) (void)hipEventDestroy(s.start);
+        if (s.stop) (void)hipEventDestroy(s.stop);
+    }
+    if (c->own_arena && c->arena) (void)hipFree(c->arena);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* fluid_last_error(const fluid_ctx* c) {
+    return c ? c->error.c_str() : g_create_error.c_str();
+}
+
+int fluid_image_bytes(const fluid_ctx* c, int image_id, uint64_t* bytes) {
+    if (!c || !bytes) return FLUID_ERR_INVALID_ARG;
+    if (image_id < 0 || image_id >= FLUID_IMAGE_COUNT) return FLUID_ERR_INVALID_ARG;
+    if (image_id >= 8) return FLUID_ERR_UNSUPPORTED;
+    *bytes = c->owned_cells() * c->img[image_id].elem_bytes;
+    return FLUID_OK;
+}
+
+int fluid_buffer_bytes(const fluid_ctx* c, int buffer_id, uint64_t* bytes) {
+    if (!c || !bytes) return FLUID_ERR_INVALID_ARG;
+    switch (buffer_id) {
+        case FLUID_BUF_PARTICLES_BUF:
+            *bytes = c->particle_capacity * 16;
+            return FLUID_OK;
+        case FLUID_BUF_SIMULATION_PARAMS_BUF:
+            *bytes = FLUID_PARAMS_BYTES;
+            return FLUID_OK;
+        case FLUID_BUF_MARCHING_CUBES_COUNTS_BUF:
+        case FLUID_BUF_MARCHING_CUBES_EDGES_BUF:
+            return FLUID_ERR_UNSUPPORTED;
+        default:
+            return FLUID_ERR_INVALID_ARG;
+    }
+}
+
+int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
+    if (bytes != want)
+        return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
+                       image_id, (unsigned long long)want, (unsigned long long)bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->plane0<uint8_t>(image_id), host, bytes, hipMemcpyHostToDevice,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_download_image(fluid_ctx* c, int image_id, void* host, uint64_t bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
+    if (bytes != want)
+        return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
+                       image_id, (unsigned long long)want, (unsigned long long)bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(host, c->plane0<uint8_t>(image_id), bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_set_params(fluid_ctx* c, const void* blob) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!blob) return c->fail(FLUID_ERR_INVALID_ARG, "null params blob");
+    fluid_params p;
+    memcpy(&p, blob, sizeof p);
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) return c->fail(rc, "%s", err.c_str());
+    for (int i = 0; i < 3; i++)
+        if (p.fluid_size[i] != c->params.fluid_size[i])
+            return c->fail(FLUID_ERR_SIZE_MISMATCH, "fluid_size cannot change on a live context");
+    c->params = p;
+    c->pk = make_params_k(p);
+    return FLUID_OK;
+}
+
+int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
+    uint64_t want = 0;
+    int rc = fluid_buffer_bytes(c, buffer_id, &want);
+    if (rc) return c->fail(rc, "buffer %d is not part of this path", buffer_id);
+    if (bytes != want)
+        return c->fail(FLUID_ERR_SIZE_MISMATCH, "buffer %d holds %llu bytes, caller passed %llu",
+                       buffer_id, (unsigned long long)want, (unsigned long long)bytes);
+    if (buffer_id == FLUID_BUF_SIMULATION_PARAMS_BUF) return fluid_set_params(c, host);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return FLUID_OK;
+}
+
+int fluid_download_buffer(fluid_ctx* c, int buffer_id, void* host, uint64_t bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
+    uint64_t want = 0;
+    int rc = fluid_buffer_bytes(c, buffer_id, &want);
+    if (rc) return c->fail(rc, "buffer %d is not part of this path", buffer_id);
+    if (bytes != want)
+        return c->fail(FLUID_ERR_SIZE_MISMATCH, "buffer %d holds %llu bytes, caller passed %llu",
+                       buffer_id, (unsigned long long)want, (unsigned long long)bytes);
+    if (buffer_id == FLUID_BUF_SIMULATION_PARAMS_BUF) {
+        memcpy(host, &c->params, FLUID_PARAMS_BYTES);
+        return FLUID_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(host, c->particles(), bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return FLUID_OK;
+}
+
+int fluid_set_pressure_iterations(fluid_ctx* c, uint32_t iterations) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    c->pressure_iterations = iterations;
+    return FLUID_OK;
+}
+
+int fluid_set_diffuse_mode(fluid_ctx* c, int mode) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (mode != FLUID_DIFFUSE_REFERENCE_EXACT && mode != FLUID_DIFFUSE_INTENDED)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown diffuse mode %d", mode);
+    c->diffuse_mode = mode;
+    return FLUID_OK;
+}
+
+int fluid_set_option(fluid_ctx* c, int option, int64_t value) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (option < 0 || option >= FLUID_OPT_COUNT)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown option %d", option);
+    c->opt[option] = value;
+    return FLUID_OK;
+}
+
+int fluid_run_section(fluid_ctx* c, int section_id) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return timed_section(c, section_id);
+}
+
+int fluid_run_pressure_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SectionTimer tm{c};
+    int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
+    if (rc) return rc;
+    rc = launch_pressure(c, is_even_iteration);
+    int rc2 = tm.end();
+    return rc ? rc : rc2;
+}
+
+int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (section_id != FLUID_SEC_12_SOLVE_PRESSURE)
+        return c->fail(FLUID_ERR_INVALID_ARG,
+                       "section %d is not a loop section (only 12_solve_pressure is)", section_id);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // FlowLoopPushConstantSection (fluid_flow_sections.h:300-313): the loop owns its own counter —
+    // dispatch k of this call has is_even_iteration = (k % 2 == 0).
+    SectionTimer tm{c};
+    int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < iterations && rc == FLUID_OK; k++)
+        rc = launch_pressure(c, (k % 2u) == 0u ? 1u : 0u);
+    c->pressure_dispatch_index = iterations;
+    int rc2 = tm.end();
+    if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && iterations > 1)
+        c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += iterations - 1;  // count dispatches
+    return rc ? rc : rc2;
+}
+
+int fluid_run_init(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    static const int order[] = {FLUID_SEC_INIT_CLEAR_VELOCITIES_1, FLUID_SEC_INIT_CLEAR_CELL_TYPES,
+                                FLUID_SEC_00_INIT_PARTICLES};
+    for (int s : order) {
+        int rc = timed_section(c, s);
+        if (rc) return rc;
+    }
+    return FLUID_OK;
+}
+
+int fluid_run_step(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // fluid_flow_sections.h:163-338, list order
+    static const int before[] = {
+        FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES, FLUID_SEC_01_UPDATE_DENSITIES,
+        FLUID_SEC_02_UPDATE_WATER, FLUID_SEC_03_UPDATE_AIR,
+        FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES, FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES,
+        FLUID_SEC_06_UPDATE_CELL_TYPES, FLUID_SEC_07_ADVECT, FLUID_SEC_08_FORCES,
+        FLUID_SEC_09_DIFFUSE, FLUID_SEC_10_SOLIDS, FLUID_SEC_11_COMPUTE_DIVERGENCE,
+        FLUID_SEC_12A_CLEAR_PRESSURES_1, FLUID_SEC_12B_CLEAR_PRESSURES_2};
+    if (c->is_slab) return slab_unsupported(c, "fluid_run_step");
+    for (int s : before) {
+        int rc = timed_section(c, s);
+        if (rc) return rc;
+    }
+    int rc = fluid_run_section_loop(c, FLUID_SEC_12_SOLVE_PRESSURE, c->pressure_iterations);
+    if (rc) return rc;
+    rc = timed_section(c, FLUID_SEC_13_FIX_DIVERGENCE);
+    if (rc) return rc;
+    return timed_section(c, FLUID_SEC_14_PARTICLES);
+}
+
+int fluid_sync(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_enable_timing(fluid_ctx* c, int enabled) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    c->timing = enabled != 0;
+    return FLUID_OK;
+}
+
+int fluid_section_time_ms(fluid_ctx* c, int section_id, double* total_ms, uint64_t* calls) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (section_id < 0 || section_id >= FLUID_SECTION_COUNT)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section_id);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = fold_timers(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->sec_ms[section_id];
+    if (calls) *calls = c->sec_calls[section_id];
+    return FLUID_OK;
+}
+
+int fluid_reset_timing(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = fold_timers(c);
+    if (rc) return rc;
+    for (int i = 0; i < FLUID_SECTION_COUNT; i++) {
+        c->sec_ms[i] = 0;
+        c->sec_calls[i] = 0;
+    }
+    return FLUID_OK;
+}
+
+int fluid_image_plane_ptr(fluid_ctx* c, int image_id, int32_t plane, void** device_ptr,
+                          uint64_t* bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    if (plane < -1 || plane > c->g.Dl)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [-1, %d]", plane, c->g.Dl);
+    const uint64_t pb = (uint64_t)c->g.plane * c->img[image_id].elem_bytes;
+    *device_ptr = c->arena + c->img[image_id].offset + (uint64_t)(plane + 1) * pb;
+    *bytes = pb;
+    return FLUID_OK;
+}
+
+int fluid_get_geometry(const fluid_ctx* c, uint32_t global_size[3], uint32_t* z_begin,
+                       uint32_t* z_count, uint64_t* capacity) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (global_size) {
+        global_size[0] = (uint32_t)c->g.W;
+        global_size[1] = (uint32_t)c->g.H;
+        global_size[2] = (uint32_t)c->g.Dg;
+    }
+    if (z_begin) *z_begin = (uint32_t)c->g.z0;
+    if (z_count) *z_count = (uint32_t)c->g.Dl;
+    if (capacity) *capacity = c->particle_capacity;
+    return FLUID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// kernels_sampler.h — the MAC-grid velocity sampler and the three passes built on it or on the
+// particle buffer: 07_advect, 14_particles, 00_init_particles, 01_update_densities.
+// Citations: /root/reference.
+#pragma once
+
+#include "device_common.h"
+
+namespace fluid {
+
+// One axis of `texture(velocities, (pos + move) / fluid_size)` with VK_FILTER_LINEAR and
+// CLAMP_TO_EDGE (fluid_flow_sections.h:95; advect.comp:52-56).  Same fp32 definition as the oracle
+// (oracle/fluid_oracle.c: axis_taps): s = coord/n; u = s*n; ub = u - 0.5; i0 = floor(ub);
+// a = ub - i0; i1 = i0 + 1; indices clamped to [0, n-1].
+__device__ __forceinline__ void axis_taps(float coord, int n, int& i0, int& i1, float& a) {
+    const float fn = (float)n;
+    const float s = coord / fn;
+    const float u = s * fn;
+    const float ub = u - 0.5f;
+    float fl = floorf(ub);
+    a = ub - fl;
+    if (!(fl >= -1.0f)) fl = -1.0f;  // also catches NaN
+    if (fl > fn) fl = fn;
+    int lo = (int)fl;
+    int hi = lo + 1;
+    lo = min(max(lo, 0), n - 1);
+    hi = min(max(hi, 0), n - 1);
+    i0 = lo;
+    i1 = hi;
+}
+__device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f - a) * A + a * B; }
+
+// Component COMP of the trilinear sample at world position (px,py,pz).  `v` addresses owned plane 0
+// of an RGBA32F image; z taps are global indices converted to local planes (whole-grid contexts
+// have z0 = 0).  The eight taps are scalar loads of one channel of the texel.
+template <int COMP>
+__device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const GridK& g, float px,
+                                             float py, float pz) {
+    const float mx = COMP == 0 ? 0.5f : 0.0f, my = COMP == 1 ? 0.5f : 0.0f,
+                mz = COMP == 2 ? 0.5f : 0.0f;
+    int x0, x1, y0, y1, z0, z1;
+    float ax, ay, az;
+    axis_taps(px + mx, g.W, x0, x1, ax);
+    axis_taps(py + my, g.H, y0, y1, ay);
+    axis_taps(pz + mz, g.Dg, z0, z1, az);
+    z0 -= g.z0;
+    z1 -= g.z0;
+    const float* __restrict__ f = reinterpret_cast<const float*>(v) + COMP;
+    const float c000 = f[4 * cidx(g, x0, y0, z0)], c100 = f[4 * cidx(g, x1, y0, z0)];
+    const float c010 = f[4 * cidx(g, x0, y1, z0)], c110 = f[4 * cidx(g, x1, y1, z0)];
+    const float c001 = f[4 * cidx(g, x0, y0, z1)], c101 = f[4 * cidx(g, x1, y0, z1)];
+    const float c011 = f[4 * cidx(g, x0, y1, z1)], c111 = f[4 * cidx(g, x1, y1, z1)];
+    const float c00 = lerp1(c000, c100, ax), c10 = lerp1(c010, c110, ax);
+    const float c01 = lerp1(c001, c101, ax), c11 = lerp1(c011, c111, ax);
+    const float c0 = lerp1(c00, c10, ay), c1 = lerp1(c01, c11, ay);
+    return lerp1(c0, c1, az);
+}
+
+template <int COMP>
+__device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
+                                                  const float4* __restrict__ v1, const GridK& g,
+                                                  const ParamsK& p, int x, int y, int lz, int gz,
+                                                  bool cur_water, float keep) {
+    const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
+    // advect.comp:65-68: move[c] = -1; cellAt(pos - move) is the cell at pos + e_c
+    const uint32_t nt =
+        type_at(t, g, x + (COMP == 0), y + (COMP == 1), lz + (COMP == 2));
+    if (pos != 0 && (cur_water || nt == p.t_water)) {
+        const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
+        const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
+        const float qz = (float)gz + (COMP == 2 ? 0.0f : 0.5f);
+        const float vx = sample_comp<0>(v1, g, qx, qy, qz);  // :75
+        const float vy = sample_comp<1>(v1, g, qx, qy, qz);
+        const float vz = sample_comp<2>(v1, g, qx, qy, qz);
+        return sample_comp<COMP>(v1, g, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt);  // :77
+    }
+    return keep;  // :79
+}
+
+// 07_advect/advect.comp:84-97
+__global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
+                           float4* __restrict__ v2, GridK g, ParamsK p) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int gz = g.z0 + lz;
+    const int64_t id = cidx(g, x, y, lz);
+    const float4 cur = v1[id];                          // :87
+    const bool cur_water = (uint32_t)t[id] == p.t_water;  // :93
+    float4 o;
+    o.x = advect_component<0>(t, v1, g, p, x, y, lz, gz, cur_water, cur.x);
+    o.y = advect_component<1>(t, v1, g, p, x, y, lz, gz, cur_water, cur.y);
+    o.z = advect_component<2>(t, v1, g, p, x, y, lz, gz, cur_water, cur.z);
+    o.w = 0.0f;
+    v2[id] = o;  // :96
+}
+
+// 14_particles/particles.comp:45-51
+__global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict__ particles,
+                              uint64_t capacity, GridK g, ParamsK p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    float4 q = particles[i];
+    if (q.w == p.active_w) {  // :48
+        const float vx = sample_comp<0>(v1, g, q.x, q.y, q.z);
+        const float vy = sample_comp<1>(v1, g, q.x, q.y, q.z);
+        const float vz = sample_comp<2>(v1, g, q.x, q.y, q.z);
+        q.x = q.x + vx * p.dt;  // :50
+        q.y = q.y + vy * p.dt;
+        q.z = q.z + vz * p.dt;
+        particles[i] = q;
+    }
+}
+
+// 00_init_particles/init_particles.comp:27-50
+__global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capacity, ParamsK p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // :48
+    if (i < (uint64_t)p.spawn_volume) {          // :39
+        uint32_t n = (uint32_t)i;                // getPos :27-34
+        const uint32_t cx = n % p.spawn_res[0];
+        n /= p.spawn_res[0];
+        const uint32_t cy = n % p.spawn_res[1];
+        n /= p.spawn_res[1];
+        const uint32_t cz = n % p.spawn_res[2];
+        // :43  offset + 1.0 * idx / resolution * size
+        o.x = p.spawn_offset[0] + ((1.0f * (float)cx) / (float)p.spawn_res[0]) * p.spawn_size[0];
+        o.y = p.spawn_offset[1] + ((1.0f * (float)cy) / (float)p.spawn_res[1]) * p.spawn_size[1];
+        o.z = p.spawn_offset[2] + ((1.0f * (float)cz) / (float)p.spawn_res[2]) * p.spawn_size[2];
+        o.w = p.active_w;  // :45
+    }
+    particles[i] = o;
+}
+
+// ivec3(pos.xyz) truncates toward zero; the imageAtomicAdd is dropped outside the image
+// (update_densities.comp:35).  trunc(v) in [0, n-1] <=> v > -1 && v < n; NaN/inf dropped.
+__device__ __forceinline__ bool trunc_index(float v, int n, int& out) {
+    if (!(v > -1.0f && v < (float)n)) return false;
+    out = (int)v;
+    return true;
+}
+
+// 01_update_densities/update_densities.comp:29-36 — particle -> cell count scatter with LDS-binned
+// atomics.  A block bins PPB consecutive particles into an LDS open-addressing table keyed by cell
+// index (ds atomics), then flushes one global atomic per touched cell.  Particles keep their spawn
+// order (x-fastest lattice), so the particles of one block land in a few hundred cells and the
+// global atomic count drops by the particles-per-cell factor.  Counts are integers: the result is
+// independent of order and identical to the per-particle atomics of the reference.
+constexpr int K01_THREADS = 256;
+constexpr int K01_PER_THREAD = 16;
+constexpr int K01_TABLE = 4096;  // entries (32 KiB of LDS: keys + counts)
+constexpr uint32_t K01_EMPTY = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(K01_THREADS)
+k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
+                     uint32_t* __restrict__ dens, GridK g, ParamsK p) {
+    __shared__ uint32_t keys[K01_TABLE];
+    __shared__ uint32_t counts[K01_TABLE];
+    for (int i = threadIdx.x; i < K01_TABLE; i += K01_THREADS) {
+        keys[i] = K01_EMPTY;
+        counts[i] = 0u;
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (K01_THREADS * K01_PER_THREAD);
+#pragma unroll 4
+    for (int k = 0; k < K01_PER_THREAD; k++) {
+        const uint64_t i = base + (uint64_t)k * K01_THREADS + threadIdx.x;  // coalesced 16-B loads
+        if (i >= capacity) break;
+        const float4 q = particles[i];
+        if (!(q.w == p.active_w)) continue;  // :33
+        int cx, cy, cz;
+        if (!(trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) && trunc_index(q.z, g.Dg, cz)))
+            continue;
+        cz -= g.z0;  // slab contexts count only their own planes
+        if ((unsigned)cz >= (unsigned)g.Dl) continue;
+        const uint32_t key = (uint32_t)cidx(g, cx, cy, cz);
+        uint32_t h = (key * 2654435761u) >> 20;  // top 12 bits -> [0, 4096)
+        bool placed = false;
+        for (int probe = 0; probe < 16; probe++) {
+            const uint32_t old = atomicCAS(&keys[h], K01_EMPTY, key);
+            if (old == K01_EMPTY || old == key) {
+                atomicAdd(&counts[h], 1u);
+                placed = true;
+                break;
+            }
+            h = (h + 1) & (K01_TABLE - 1);
+        }
+        if (!placed) atomicAdd(&dens[key], 1u);  // table crowded: fall through to a global atomic
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K01_TABLE; i += K01_THREADS) {
+        const uint32_t key = keys[i];
+        if (key != K01_EMPTY) atomicAdd(&dens[key], counts[i]);
+    }
+}
+
+}  // namespace fluid

@@ -1,0 +1,324 @@
+"""ctypes binding of the engine's C ABI (include/fluid_engine.h) — plumbing only.
+
+The product is ``libfluid_engine.so`` (HIP kernels + C++ host, csrc/).  This module loads it,
+declares every exported symbol, and wraps a context in a small class whose method names follow the
+reference's section lists (/root/reference/fluid_flow_sections.h:136-338).  There is no fallback:
+if the library is missing or no gfx950 device is present, construction raises.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .params import PARAMS_BYTES, FluidParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfluid_engine.so")
+
+# ---- enums of include/fluid_engine.h -------------------------------------------------------------
+# ImageAttachments / BufferAttachments, fluid_flow_sections.h:10-16
+VELOCITIES_1, VELOCITIES_2, CELL_TYPES, NEW_CELL_TYPES = 0, 1, 2, 3
+PRESSURES_1, PRESSURES_2, DIVERGENCES, PARTICLE_DENSITIES_IMG = 4, 5, 6, 7
+DETAILED_DENSITIES_IMG, DETAILED_DENSITIES_INERTIA_IMG = 8, 9
+PARTICLE_DENSITIES_FLOAT_1, PARTICLE_DENSITIES_FLOAT_2 = 10, 11
+IMAGE_COUNT = 12
+PARTICLES_BUF, MARCHING_CUBES_COUNTS_BUF, MARCHING_CUBES_EDGES_BUF, SIMULATION_PARAMS_BUF = 0, 1, 2, 3
+
+IMAGE_DTYPES = {
+    VELOCITIES_1: (np.float32, 4), VELOCITIES_2: (np.float32, 4),
+    CELL_TYPES: (np.uint8, 1), NEW_CELL_TYPES: (np.uint8, 1),
+    PRESSURES_1: (np.float32, 1), PRESSURES_2: (np.float32, 1), DIVERGENCES: (np.float32, 1),
+    PARTICLE_DENSITIES_IMG: (np.uint32, 1),
+}
+
+SECTION_NAMES = [
+    "init_clear_velocities_1", "init_clear_cell_types", "00_init_particles",
+    "01a_clear_particle_densities", "01_update_densities", "02_update_water", "03_update_air",
+    "04_compute_extrapolated_velocities", "05_set_extrapolated_velocities", "06_update_cell_types",
+    "07_advect", "08_forces", "09_diffuse", "10_solids", "11_compute_divergence",
+    "12a_clear_pressures_1", "12b_clear_pressures_2", "12_solve_pressure", "13_fix_divergence",
+    "14_particles",
+]
+SECTION_IDS = {name: i for i, name in enumerate(SECTION_NAMES)}
+SEC_12_SOLVE_PRESSURE = SECTION_IDS["12_solve_pressure"]
+SECTION_COUNT = len(SECTION_NAMES)
+
+DIFFUSE_REFERENCE_EXACT, DIFFUSE_INTENDED = 0, 1
+OPT_PRESSURE_KERNEL = 0
+
+OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
+    0, -1, -2, -3, -4, -5, -6)
+
+# every symbol include/fluid_engine.h declares
+EXPORTED_SYMBOLS = [
+    "fluid_abi_version", "fluid_params_default", "fluid_required_arena_bytes", "fluid_create",
+    "fluid_destroy", "fluid_last_error", "fluid_upload_image", "fluid_download_image",
+    "fluid_upload_buffer", "fluid_download_buffer", "fluid_image_bytes", "fluid_buffer_bytes",
+    "fluid_set_params", "fluid_set_pressure_iterations", "fluid_set_diffuse_mode",
+    "fluid_run_section", "fluid_run_section_loop", "fluid_run_pressure_dispatch", "fluid_run_init",
+    "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
+    "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_get_geometry", "fluid_set_option",
+]
+
+
+class CreateInfo(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32),
+        ("device", C.c_int32),
+        ("params_blob", C.c_void_p),
+        ("particle_capacity", C.c_uint64),
+        ("pressure_iterations", C.c_uint32),
+        ("slab_z_begin", C.c_uint32),
+        ("slab_z_count", C.c_uint32),
+        ("hip_stream", C.c_void_p),
+        ("arena", C.c_void_p),
+        ("arena_bytes", C.c_uint64),
+    ]
+
+
+class FluidEngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"fluid engine error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libfluid_engine.so and declare the ABI.  Raises if the library has not been built
+    (run ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C …/csrc``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: the HIP engine has not been built (make -C "
+            f"{os.path.join(_HERE, 'csrc')}); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+    sig = {
+        "fluid_abi_version": (C.c_int, []),
+        "fluid_params_default": (C.c_int, [vp, u32, u32, u32, u32]),
+        "fluid_required_arena_bytes": (u64, [C.POINTER(CreateInfo)]),
+        "fluid_create": (C.c_int, [C.POINTER(vp), C.POINTER(CreateInfo)]),
+        "fluid_destroy": (None, [vp]),
+        "fluid_last_error": (C.c_char_p, [vp]),
+        "fluid_upload_image": (C.c_int, [vp, C.c_int, vp, u64]),
+        "fluid_download_image": (C.c_int, [vp, C.c_int, vp, u64]),
+        "fluid_upload_buffer": (C.c_int, [vp, C.c_int, vp, u64]),
+        "fluid_download_buffer": (C.c_int, [vp, C.c_int, vp, u64]),
+        "fluid_image_bytes": (C.c_int, [vp, C.c_int, C.POINTER(u64)]),
+        "fluid_buffer_bytes": (C.c_int, [vp, C.c_int, C.POINTER(u64)]),
+        "fluid_set_params": (C.c_int, [vp, vp]),
+        "fluid_set_pressure_iterations": (C.c_int, [vp, u32]),
+        "fluid_set_diffuse_mode": (C.c_int, [vp, C.c_int]),
+        "fluid_run_section": (C.c_int, [vp, C.c_int]),
+        "fluid_run_section_loop": (C.c_int, [vp, C.c_int, u32]),
+        "fluid_run_pressure_dispatch": (C.c_int, [vp, u32]),
+        "fluid_run_init": (C.c_int, [vp]),
+        "fluid_run_step": (C.c_int, [vp]),
+        "fluid_sync": (C.c_int, [vp]),
+        "fluid_enable_timing": (C.c_int, [vp, C.c_int]),
+        "fluid_section_time_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "fluid_reset_timing": (C.c_int, [vp]),
+        "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
+        "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
+                                         C.POINTER(u64)]),
+        "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+class FluidEngine:
+    """One engine context = one GPU (optionally one Z-slab of the global grid).
+
+    Mirrors how main.cpp drives the reference: construct (SimulationDescriptors + params upload,
+    fluid_flow_sections.h:26-96), ``run_init()`` once (main.cpp:111), ``run_step()`` per frame
+    (main.cpp:172); individual sections by name via ``run_section``."""
+
+    def __init__(self, params: FluidParams, particle_capacity: int = 0,
+                 pressure_iterations: int = 200, device: int = -1,
+                 slab: Optional[tuple] = None, stream: int = 0, arena: int = 0,
+                 arena_bytes: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self._blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
+        info = CreateInfo()
+        info.struct_bytes = C.sizeof(CreateInfo)
+        info.device = device
+        info.params_blob = C.cast(self._blob, C.c_void_p)
+        info.particle_capacity = particle_capacity
+        info.pressure_iterations = pressure_iterations
+        if slab is not None:
+            info.slab_z_begin, info.slab_z_count = int(slab[0]), int(slab[1])
+        info.hip_stream = stream or None
+        info.arena = arena or None
+        info.arena_bytes = arena_bytes
+        rc = self._lib.fluid_create(C.byref(self._h), C.byref(info))
+        if rc != OK:
+            msg = self._lib.fluid_last_error(None)
+            self._h = C.c_void_p()
+            raise FluidEngineError(rc, msg.decode() if msg else "fluid_create failed")
+        self.params = params.copy()
+        size = (C.c_uint32 * 3)()
+        z0, zc, cap = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self._check(self._lib.fluid_get_geometry(self._h, C.byref(size), C.byref(z0), C.byref(zc),
+                                                 C.byref(cap)))
+        self.global_size = (int(size[0]), int(size[1]), int(size[2]))
+        self.slab_z_begin, self.slab_z_count = int(z0.value), int(zc.value)
+        self.particle_capacity = int(cap.value)
+
+    # -- helpers --------------------------------------------------------------------------------
+    @staticmethod
+    def required_arena_bytes(params: FluidParams, particle_capacity: int = 0,
+                             slab: Optional[tuple] = None) -> int:
+        lib = load_library()
+        blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
+        info = CreateInfo()
+        info.struct_bytes = C.sizeof(CreateInfo)
+        info.params_blob = C.cast(blob, C.c_void_p)
+        info.particle_capacity = particle_capacity
+        if slab is not None:
+            info.slab_z_begin, info.slab_z_count = int(slab[0]), int(slab[1])
+        return int(lib.fluid_required_arena_bytes(C.byref(info)))
+
+    def _check(self, rc: int):
+        if rc != OK:
+            msg = self._lib.fluid_last_error(self._h)
+            raise FluidEngineError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fluid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def local_shape(self):
+        w, h, _ = self.global_size
+        return (self.slab_z_count, h, w)
+
+    # -- data movement --------------------------------------------------------------------------
+    def image_shape(self, image_id: int):
+        dtype, ch = IMAGE_DTYPES[image_id]
+        shape = self.local_shape + ((ch,) if ch > 1 else ())
+        return dtype, shape
+
+    def upload_image(self, image_id: int, array: np.ndarray):
+        if image_id in IMAGE_DTYPES:
+            dtype, shape = self.image_shape(image_id)
+            array = np.ascontiguousarray(array, dtype=dtype)
+            if array.size != int(np.prod(shape)):
+                raise FluidEngineError(ERR_SIZE_MISMATCH,
+                                       f"image {image_id} expects shape {shape}, got {array.shape}")
+        else:
+            array = np.ascontiguousarray(array)
+        self._check(self._lib.fluid_upload_image(self._h, image_id, array.ctypes.data,
+                                                 array.nbytes))
+
+    def download_image(self, image_id: int) -> np.ndarray:
+        if image_id not in IMAGE_DTYPES:
+            self._check(self._lib.fluid_download_image(self._h, image_id, None, 0))
+        dtype, shape = self.image_shape(image_id)
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.fluid_download_image(self._h, image_id, out.ctypes.data, out.nbytes))
+        return out
+
+    def upload_particles(self, particles: np.ndarray):
+        particles = np.ascontiguousarray(particles, dtype=np.float32)
+        self._check(self._lib.fluid_upload_buffer(self._h, PARTICLES_BUF, particles.ctypes.data,
+                                                  particles.nbytes))
+
+    def download_particles(self) -> np.ndarray:
+        out = np.empty((self.particle_capacity, 4), dtype=np.float32)
+        self._check(self._lib.fluid_download_buffer(self._h, PARTICLES_BUF, out.ctypes.data,
+                                                    out.nbytes))
+        return out
+
+    def set_params(self, params: FluidParams):
+        blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
+        self._check(self._lib.fluid_set_params(self._h, C.cast(blob, C.c_void_p)))
+        self.params = params.copy()
+
+    def download_params(self) -> FluidParams:
+        blob = (C.c_uint8 * PARAMS_BYTES)()
+        self._check(self._lib.fluid_download_buffer(self._h, SIMULATION_PARAMS_BUF,
+                                                    C.cast(blob, C.c_void_p), PARAMS_BYTES))
+        return FluidParams.from_bytes(bytes(blob))
+
+    # -- sections ---------------------------------------------------------------------------------
+    def run_section(self, section):
+        sid = SECTION_IDS[section] if isinstance(section, str) else int(section)
+        self._check(self._lib.fluid_run_section(self._h, sid))
+
+    def run_section_loop(self, section, iterations: int):
+        sid = SECTION_IDS[section] if isinstance(section, str) else int(section)
+        self._check(self._lib.fluid_run_section_loop(self._h, sid, iterations))
+
+    def solve_pressure(self, iterations: int):
+        """The 12_solve_pressure loop section (fluid_flow_sections.h:300-313)."""
+        self.run_section_loop(SEC_12_SOLVE_PRESSURE, iterations)
+
+    def run_pressure_dispatch(self, is_even_iteration: int):
+        self._check(self._lib.fluid_run_pressure_dispatch(self._h, is_even_iteration))
+
+    def run_init(self):
+        self._check(self._lib.fluid_run_init(self._h))
+
+    def run_step(self):
+        self._check(self._lib.fluid_run_step(self._h))
+
+    def sync(self):
+        self._check(self._lib.fluid_sync(self._h))
+
+    def set_pressure_iterations(self, iterations: int):
+        self._check(self._lib.fluid_set_pressure_iterations(self._h, iterations))
+
+    def set_diffuse_mode(self, mode: int):
+        self._check(self._lib.fluid_set_diffuse_mode(self._h, mode))
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.fluid_set_option(self._h, option, value))
+
+    # -- timing -----------------------------------------------------------------------------------
+    def enable_timing(self, enabled: bool = True):
+        self._check(self._lib.fluid_enable_timing(self._h, 1 if enabled else 0))
+
+    def reset_timing(self):
+        self._check(self._lib.fluid_reset_timing(self._h))
+
+    def section_time_ms(self, section):
+        sid = SECTION_IDS[section] if isinstance(section, str) else int(section)
+        ms, calls = C.c_double(), C.c_uint64()
+        self._check(self._lib.fluid_section_time_ms(self._h, sid, C.byref(ms), C.byref(calls)))
+        return float(ms.value), int(calls.value)
+
+    def section_times(self):
+        return {name: self.section_time_ms(i) for i, name in enumerate(SECTION_NAMES)}
+
+    # -- multi-GPU plumbing ---------------------------------------------------------------------------
+    def image_plane_ptr(self, image_id: int, plane: int):
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.fluid_image_plane_ptr(self._h, image_id, plane, C.byref(ptr),
+                                                    C.byref(nbytes)))
+        return int(ptr.value), int(nbytes.value)
