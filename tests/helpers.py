@@ -1,0 +1,109 @@
+"""Shared helpers for the parity tests: random scenes, engine <-> oracle state transfer, bitwise
+comparison.  The engine is always driven through its C ABI (ctypes binding in
+vulkan-3d-fluid-simulation_amd/engine.py)."""
+import numpy as np
+
+import fluid_amd
+from fluid_amd import engine as E
+from fluid_amd.params import CELL_AIR, CELL_INACTIVE, CELL_SOLID, CELL_WATER
+from oracle_binding import OracleState
+
+IMAGE_FIELDS = {
+    "velocities_1": E.VELOCITIES_1, "velocities_2": E.VELOCITIES_2, "cell_types": E.CELL_TYPES,
+    "new_cell_types": E.NEW_CELL_TYPES, "pressures_1": E.PRESSURES_1,
+    "pressures_2": E.PRESSURES_2, "divergences": E.DIVERGENCES,
+    "particle_densities": E.PARTICLE_DENSITIES_IMG,
+}
+
+
+def random_state(size, capacity=0, seed=0, iters=6, water_fraction=0.45, solid_walls=True,
+                 velocity_scale=3.0) -> OracleState:
+    """A scene that exercises every branch: a random mix of all four cell types in both type maps,
+    random velocities/pressures/divergences/densities, particles inside, on the edge of and outside
+    the grid, active and inactive."""
+    w, h, d = size
+    p = fluid_amd.default_params(w, h, d, capacity)
+    p.fountain_position[:] = (w // 2, max(h - 2, 0), d // 2)
+    s = OracleState(p, capacity, iters)
+    rng = np.random.default_rng(seed)
+    probs = [0.15, 0.25, water_fraction, 0.15]
+    probs = np.array(probs) / np.sum(probs)
+    kinds = np.array([CELL_INACTIVE, CELL_AIR, CELL_WATER, CELL_SOLID], np.uint8)
+    s.cell_types[...] = rng.choice(kinds, size=s.shape, p=probs)
+    s.new_cell_types[...] = rng.choice(kinds, size=s.shape, p=probs)
+    if solid_walls:
+        for t in (s.cell_types,):
+            t[0], t[-1] = CELL_SOLID, CELL_SOLID
+            t[:, 0], t[:, -1] = CELL_SOLID, CELL_SOLID
+            t[:, :, 0], t[:, :, -1] = CELL_SOLID, CELL_SOLID
+    # make sure the fountain cell is wet in some scenes
+    fx, fy, fz = p.fountain_position[:]
+    if fz < d and fy < h and fx < w and seed % 2 == 0:
+        s.cell_types[fz, fy, fx] = CELL_WATER
+    s.velocities_1[...] = (velocity_scale * rng.standard_normal(s.velocities_1.shape)).astype(np.float32)
+    s.velocities_2[...] = (velocity_scale * rng.standard_normal(s.velocities_2.shape)).astype(np.float32)
+    s.pressures_1[...] = rng.uniform(0.0, 2.0, s.shape).astype(np.float32)
+    s.pressures_2[...] = rng.uniform(0.0, 2.0, s.shape).astype(np.float32)
+    s.divergences[...] = rng.uniform(-1.0, 1.0, s.shape).astype(np.float32)
+    s.particle_densities[...] = rng.integers(0, 3, s.shape).astype(np.uint32)
+    if capacity:
+        pos = rng.uniform(-1.5, 1.5 + max(size), (capacity, 3)).astype(np.float32)
+        inside = rng.uniform(0, 1, (capacity, 3)).astype(np.float32) * np.array(size, np.float32)
+        pick = rng.uniform(0, 1, capacity) < 0.8
+        pos[pick] = inside[pick]
+        s.particles[:, :3] = pos
+        s.particles[:, 3] = np.where(rng.uniform(0, 1, capacity) < 0.85, 1.0, 0.0)
+        # a few particles exactly on cell and domain boundaries
+        k = min(capacity, 6)
+        s.particles[:k, :3] = np.array([[0, 0, 0], [w, 1, 1], [w - 1, h - 1, d - 1],
+                                        [-0.5, 0.5, 0.5], [1.0, 2.0, 3.0],
+                                        [w - 0.001, 0.0, 0.0]], np.float32)[:k]
+        s.particles[:k, 3] = 1.0
+    return s
+
+
+def make_engine(state: OracleState, **kw) -> "fluid_amd.FluidEngine":
+    eng = fluid_amd.FluidEngine(state.params, particle_capacity=state.capacity,
+                                pressure_iterations=state.pressure_iterations, **kw)
+    eng.set_diffuse_mode(state.diffuse_mode)
+    upload_state(eng, state)
+    return eng
+
+
+def upload_state(eng, state: OracleState, fields=None):
+    for name, img in IMAGE_FIELDS.items():
+        if fields is None or name in fields:
+            eng.upload_image(img, getattr(state, name))
+    if state.capacity and (fields is None or "particles" in fields):
+        eng.upload_particles(state.particles)
+
+
+def download_state(eng, state_like: OracleState) -> dict:
+    out = {name: eng.download_image(img) for name, img in IMAGE_FIELDS.items()}
+    out["particles"] = (eng.download_particles() if state_like.capacity
+                        else np.zeros((0, 4), np.float32))
+    return out
+
+
+def bits(a: np.ndarray) -> np.ndarray:
+    """Integer view for bit-exact comparison (NaN == NaN, -0 != +0)."""
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    return a
+
+
+def assert_bit_equal(got: np.ndarray, exp: np.ndarray, what: str):
+    assert got.shape == exp.shape, f"{what}: shape {got.shape} != {exp.shape}"
+    gb, eb = bits(np.ascontiguousarray(got)), bits(np.ascontiguousarray(exp))
+    if not np.array_equal(gb, eb):
+        bad = np.argwhere(gb != eb)
+        first = tuple(bad[0])
+        raise AssertionError(
+            f"{what}: {len(bad)} of {gb.size} elements differ; first at {first}: "
+            f"got {got[first]!r} expected {exp[first]!r}")
+
+
+def assert_state_equal(eng, state: OracleState, fields=None, ctx=""):
+    got = download_state(eng, state)
+    for name in (fields or list(IMAGE_FIELDS) + ["particles"]):
+        assert_bit_equal(got[name], getattr(state, name), f"{ctx}{name}")

@@ -1,0 +1,292 @@
+"""Parity of the HIP engine against the CPU oracle, through the C ABI.  Needs an MI355X.
+
+Tolerance: BIT-EXACT for every field, integer and fp32 alike.  Both sides evaluate the shader
+arithmetic in fp32 with one rounding per operation in source order (-ffp-contract=off, IEEE
+division), so the stated north-star tolerance ("a stated float tolerance per field") is 0 ulp here;
+any mismatch is a bug, not noise.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import fluid_amd
+from fluid_amd import engine as E
+from fluid_amd import scenes
+from fluid_amd.params import CELL_AIR, CELL_SOLID, CELL_WATER, dam_break_params, default_params
+from helpers import (IMAGE_FIELDS, assert_bit_equal, assert_state_equal, download_state,
+                     make_engine, random_state, upload_state)
+from oracle_binding import OracleState
+
+pytestmark = pytest.mark.gpu
+
+GRID_SECTIONS = ["02_update_water", "03_update_air", "04_compute_extrapolated_velocities",
+                 "05_set_extrapolated_velocities", "06_update_cell_types", "07_advect",
+                 "08_forces", "09_diffuse", "10_solids", "11_compute_divergence",
+                 "13_fix_divergence"]
+CLEAR_SECTIONS = ["init_clear_velocities_1", "init_clear_cell_types",
+                  "01a_clear_particle_densities", "12a_clear_pressures_1", "12b_clear_pressures_2"]
+PARTICLE_SECTIONS = ["00_init_particles", "01_update_densities", "14_particles"]
+
+SIZES = [(24, 20, 16), (17, 13, 9), (64, 8, 5), (5, 5, 5), (260, 6, 4)]
+
+
+@pytest.mark.parametrize("size", SIZES)
+@pytest.mark.parametrize("section", GRID_SECTIONS + CLEAR_SECTIONS + PARTICLE_SECTIONS)
+def test_section_matches_oracle(section, size):
+    cap = 3000
+    st = random_state(size, capacity=cap, seed=zlib.crc32(repr((section, size)).encode()) % 1000)
+    if section == "00_init_particles":
+        st.params.particle_spawn_cube_resolution[:] = (13, 11, 17)
+        st.params.particle_spawn_cube_volume = 13 * 11 * 17  # < capacity: tail becomes inactive
+        st.params.particle_spawn_cube_offset[:] = (0.3 * size[0], 0.1 * size[1], 0.2 * size[2])
+        st.params.particle_spawn_cube_size[:] = (0.5 * size[0], 0.6 * size[1], 0.3 * size[2])
+    with make_engine(st) as eng:
+        eng.run_section(section)
+        st.run_section(section)
+        assert_state_equal(eng, st, ctx=f"{section} {size}: ")
+
+
+@pytest.mark.parametrize("size", [(24, 20, 16), (17, 13, 9)])
+def test_diffuse_intended_mode(size):
+    st = random_state(size, seed=11)
+    st.diffuse_mode = E.DIFFUSE_INTENDED
+    with make_engine(st) as eng:
+        eng.run_section("09_diffuse")
+        st.run_section("09_diffuse")
+        assert_state_equal(eng, st, ctx="09_diffuse intended: ")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("size", [(24, 20, 16), (64, 64, 64), (260, 12, 9), (512, 6, 3)])
+@pytest.mark.parametrize("iters", [1, 2, 7])
+def test_pressure_loop_matches_oracle(variant, size, iters):
+    st = random_state(size, seed=iters + 17 * variant)
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+        eng.solve_pressure(iters)
+        st.solve_pressure(iters)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"],
+                           ctx=f"12 x{iters} variant {variant} {size}: ")
+
+
+def test_pressure_odd_width_uses_plain_kernel():
+    st = random_state((17, 13, 9), seed=5)
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_PRESSURE_KERNEL, 2)  # z-march needs W % 4 == 0: engine falls back
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"])
+
+
+def test_pressure_dispatch_counter_and_explicit_push_constant():
+    st = random_state((24, 20, 16), seed=3)
+    with make_engine(st) as eng:
+        # after 12a/12b the section's own counter starts at "even" 
+        eng.run_section("12a_clear_pressures_1")
+        eng.run_section("12b_clear_pressures_2")
+        st.run_section("12a_clear_pressures_1")
+        st.run_section("12b_clear_pressures_2")
+        for k in range(3):
+            eng.run_section("12_solve_pressure")
+            st.pressure_dispatch(1 if k % 2 == 0 else 0)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="counter: ")
+        eng.run_pressure_dispatch(0)
+        st.pressure_dispatch(0)
+        eng.run_pressure_dispatch(7)  # anything but 1 reads P2 (pressure.comp:71)
+        st.pressure_dispatch(7)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="explicit: ")
+
+
+def test_pressure_walled_in_cell_produces_the_same_inf_nan():
+    st = random_state((24, 20, 16), seed=8)
+    st.cell_types[4:7, 4:7, 4:7] = CELL_SOLID
+    st.cell_types[5, 5, 5] = CELL_WATER
+    st.divergences[5, 5, 5] = 0.0  # -0/0 -> NaN
+    st.cell_types[9:12, 9:12, 9:12] = CELL_SOLID
+    st.cell_types[10, 10, 10] = CELL_WATER
+    st.divergences[10, 10, 10] = 0.25  # -s/0 -> -inf
+    for variant in (1, 2):
+        s2 = st.copy()
+        with make_engine(s2) as eng, np.errstate(all="ignore"):
+            eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.solve_pressure(3)
+            s2.solve_pressure(3)
+            assert np.isnan(s2.pressures_2[5, 5, 5]) and np.isinf(s2.pressures_2[10, 10, 10])
+            assert_state_equal(eng, s2, fields=["pressures_1", "pressures_2"])
+
+
+@pytest.mark.parametrize("size,iters,steps", [((32, 32, 32), 20, 3), ((24, 40, 20), 7, 2)])
+def test_full_step_dam_break_matches_oracle(size, iters, steps):
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.run_init()
+        st.run_init()
+        assert_state_equal(eng, st, fields=["velocities_1", "cell_types", "particles"], ctx="init: ")
+        for k in range(steps):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"step {k}: ")
+        assert np.count_nonzero(st.cell_types == CELL_WATER) > 100  # the scene is not trivial
+
+
+def test_c1_config_64cubed_40_iterations():
+    """BASELINE.json configs[0]: 64^3, 8 particles/cell, 40 Jacobi iterations."""
+    p, cap = dam_break_params(64, 64, 64)
+    st = OracleState(p, cap, 40)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=40) as eng:
+        eng.run_init()
+        st.run_init()
+        for k in range(2):
+            eng.run_step()
+            st.run_step()
+        assert_state_equal(eng, st, ctx="C1: ")
+    water = np.count_nonzero(st.cell_types == CELL_WATER)
+    assert abs(cap / water - 8.0) < 1.5  # ~8 particles per water cell
+
+
+def test_step_by_sections_equals_run_step():
+    p, cap = dam_break_params(32, 32, 32)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=10) as a, \
+            fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=10) as b:
+        a.run_init()
+        b.run_init()
+        for _ in range(2):
+            a.run_step()
+            for s in OracleState.STEP_BEFORE_12:
+                b.run_section(s)
+            b.run_section_loop("12_solve_pressure", 10)
+            for s in OracleState.STEP_AFTER_12:
+                b.run_section(s)
+        ref = OracleState(p, cap, 10)
+        ga, gb = download_state(a, ref), download_state(b, ref)
+        for k in ga:
+            assert_bit_equal(ga[k], gb[k], k)
+
+
+def test_no_particles_and_empty_grid_fixed_point():
+    p = default_params(16, 16, 16, 0)
+    st = OracleState(p, 0, 4)
+    with fluid_amd.FluidEngine(p, particle_capacity=0, pressure_iterations=4) as eng:
+        assert eng.particle_capacity == 0 or True
+        eng.run_init()
+        st.run_init()
+        eng.run_step()
+        st.run_step()
+        assert_state_equal(eng, st, fields=list(IMAGE_FIELDS))
+
+
+def test_golden_fixture_matches_engine():
+    """The committed golden vectors (tests/golden, produced by the oracle) against the engine."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "dam_break_16_steps3.npz")
+    g = np.load(path)
+    size = tuple(int(v) for v in g["size"])
+    iters = int(g["iterations"])
+    p, cap = dam_break_params(*size)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.run_init()
+        for _ in range(int(g["steps"])):
+            eng.run_step()
+        got = download_state(eng, OracleState(p, cap, iters))
+        for name in list(IMAGE_FIELDS) + ["particles"]:
+            assert_bit_equal(got[name], g[name], f"golden {name}")
+
+
+# ---- full-size checks through size-independent properties ---------------------------------------
+def test_pressure_256cubed_variants_agree_and_window_matches_oracle():
+    """256^3 full-fluid grid (BASELINE config C3 shape), 8 sweeps: (a) the z-marching kernel and
+    the plain kernel — two independent HIP implementations — agree bit for bit everywhere;
+    (b) a 24-plane window re-computed by the oracle matches on the planes outside the window's
+    dependence cone (8 sweeps reach 8 planes)."""
+    n, iters = 256, 8
+    p = default_params(n, n, n, 0)
+    shape = (n, n, n)
+    t = scenes.full_fluid_types(shape)
+    div = scenes.full_fluid_divergence(shape)
+    results = {}
+    for variant in (1, 2, 3):
+        with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
+            eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.upload_image(E.CELL_TYPES, t)
+            eng.upload_image(E.DIVERGENCES, div)
+            eng.run_section("12a_clear_pressures_1")
+            eng.run_section("12b_clear_pressures_2")
+            eng.solve_pressure(iters)
+            results[variant] = (eng.download_image(E.PRESSURES_1), eng.download_image(E.PRESSURES_2))
+    for variant in (2, 3):
+        assert_bit_equal(results[variant][0], results[1][0], f"P1 variant {variant} vs plain")
+        assert_bit_equal(results[variant][1], results[1][1], f"P2 variant {variant} vs plain")
+    z0, zc = 100, 24
+    pw = default_params(n, n, zc, 0)
+    sw = OracleState(pw, 0, iters)
+    sw.cell_types[...] = t[z0:z0 + zc]
+    sw.divergences[...] = div[z0:z0 + zc]
+    sw.pressures_1[...] = 1.0
+    sw.pressures_2[...] = 1.0
+    sw.solve_pressure(iters)
+    lo, hi = iters, zc - iters
+    assert_bit_equal(results[2][0][z0 + lo:z0 + hi], sw.pressures_1[lo:hi], "window P1")
+    assert_bit_equal(results[2][1][z0 + lo:z0 + hi], sw.pressures_2[lo:hi], "window P2")
+    # and the iteration is doing something: pressures moved away from p_air
+    assert np.count_nonzero(results[2][0] != 1.0) > 0.9 * (n - 2) ** 3
+
+
+def test_pressure_all_air_is_untouched_and_all_water_converges_to_fixed_point():
+    """Properties that hold at any size: (a) without water nothing is written; (b) with zero
+    divergence and p = p_air everywhere, p_air is a fixed point (every neighbour sum is exact)."""
+    n = 128
+    p = default_params(n, n, n, 0)
+    with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
+        eng.upload_image(E.CELL_TYPES, np.full((n, n, n), CELL_AIR, np.uint8))
+        rng = np.random.default_rng(0)
+        p1 = rng.uniform(0, 2, (n, n, n)).astype(np.float32)
+        eng.upload_image(E.PRESSURES_1, p1)
+        eng.upload_image(E.PRESSURES_2, p1 + 1)
+        eng.upload_image(E.DIVERGENCES, rng.uniform(-1, 1, (n, n, n)).astype(np.float32))
+        eng.solve_pressure(4)
+        assert_bit_equal(eng.download_image(E.PRESSURES_1), p1, "all air P1")
+        assert_bit_equal(eng.download_image(E.PRESSURES_2), p1 + 1, "all air P2")
+        eng.upload_image(E.CELL_TYPES, scenes.full_fluid_types((n, n, n)))
+        eng.upload_image(E.DIVERGENCES, np.zeros((n, n, n), np.float32))
+        eng.run_section("12a_clear_pressures_1")
+        eng.run_section("12b_clear_pressures_2")
+        eng.solve_pressure(10)
+        assert np.all(eng.download_image(E.PRESSURES_1) == 1.0)
+        assert np.all(eng.download_image(E.PRESSURES_2) == 1.0)
+
+
+# ---- the ABI's error behaviour on a live context ----------------------------------------------------
+def test_error_codes_and_messages():
+    p = default_params(16, 16, 16, 10)
+    with fluid_amd.FluidEngine(p, particle_capacity=10) as eng:
+        with pytest.raises(fluid_amd.FluidEngineError) as ei:
+            eng.upload_image(E.PRESSURES_1, np.zeros(7, np.float32))
+        assert ei.value.code == E.ERR_SIZE_MISMATCH
+        with pytest.raises(fluid_amd.FluidEngineError) as ei:
+            eng.run_section(99)
+        assert ei.value.code == E.ERR_INVALID_ARG
+        with pytest.raises(fluid_amd.FluidEngineError) as ei:
+            eng.download_image(E.DETAILED_DENSITIES_IMG)
+        assert ei.value.code == E.ERR_UNSUPPORTED
+        with pytest.raises(fluid_amd.FluidEngineError) as ei:
+            eng.run_section_loop("11_compute_divergence", 3)
+        assert ei.value.code == E.ERR_INVALID_ARG and "loop" in str(ei.value)
+        blob = eng.download_params()
+        assert blob.to_bytes() == p.to_bytes()
+
+
+def test_timing_counts_sections():
+    p, cap = dam_break_params(32, 32, 32)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=6) as eng:
+        eng.enable_timing(True)
+        eng.run_init()
+        eng.run_step()
+        eng.run_step()
+        times = eng.section_times()
+        assert times["12_solve_pressure"][1] == 12
+        assert times["07_advect"][1] == 2 and times["07_advect"][0] > 0
+        assert times["00_init_particles"][1] == 1
+        eng.reset_timing()
+        assert eng.section_time_ms("07_advect") == (0.0, 0)

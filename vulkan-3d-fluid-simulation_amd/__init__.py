@@ -8,5 +8,6 @@ The directory name carries hyphens (it mirrors the reference repository's name),
 from . import params  # noqa: F401
 from .params import FluidParams, dam_break_params, default_params  # noqa: F401
 from . import engine  # noqa: F401
+from . import scenes  # noqa: F401
 from .engine import FluidEngine, FluidEngineError, load_library  # noqa: F401
 from .build import build_engine  # noqa: F401

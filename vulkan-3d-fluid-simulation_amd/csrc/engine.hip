@@ -681,9 +681,9 @@ int fluid_buffer_bytes(const fluid_ctx* c, int buffer_id, uint64_t* bytes) {
 
 int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t bytes) {
     if (!c) return FLUID_ERR_INVALID_ARG;
-    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
     int rc = check_image(c, image_id);
     if (rc) return rc;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
     const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
     if (bytes != want)
         return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
@@ -697,9 +697,9 @@ int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t by
 
 int fluid_download_image(fluid_ctx* c, int image_id, void* host, uint64_t bytes) {
     if (!c) return FLUID_ERR_INVALID_ARG;
-    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
     int rc = check_image(c, image_id);
     if (rc) return rc;
+    if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
     const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
     if (bytes != want)
         return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",

@@ -13,24 +13,29 @@ SEED_JACOBI = 0x5EED0012
 
 
 def splitmix64(counter: np.ndarray, seed: int) -> np.ndarray:
-    """Vectorised SplitMix64: the n-th output of the generator seeded with `seed`."""
+    """Vectorised SplitMix64: the n-th output (n = counter) of the generator seeded with `seed`."""
     with np.errstate(over="ignore"):
-        z = (np.uint64(seed) + (counter.astype(np.uint64) + np.uint64(1))
-             * np.uint64(0x9E3779B97F4A7C15))
+        z = (counter.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z += np.uint64(seed)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
 
 
 def uniform_pm1(n: int, seed: int, offset: int = 0) -> np.ndarray:
-    """n floats in [-1, 1): top 24 bits of SplitMix64 -> exactly representable fp32."""
+    """n floats in [-1, 1): top 24 bits of SplitMix64 output number offset+i -> exact fp32.
+    (int64 arange / int64->float32 conversions: numpy's uint64 paths are ~50x slower.)"""
     out = np.empty(n, np.float32)
-    chunk = 1 << 24
+    chunk = 1 << 22
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
-        bits = splitmix64(np.arange(offset + s, offset + e, dtype=np.uint64), seed)
-        out[s:e] = ((bits >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -23)
-                    - np.float32(1.0))
+        ctr = np.arange(offset + s, offset + e, dtype=np.int64).view(np.uint64)
+        bits = splitmix64(ctr, seed)
+        bits >>= np.uint64(40)
+        o = out[s:e]
+        o[:] = bits.view(np.int64)
+        o *= np.float32(2.0 ** -23)
+        o -= np.float32(1.0)
     return out
 
 
