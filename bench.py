@@ -179,6 +179,9 @@ def main():
             }
             print(json.dumps(out), flush=True)
         solver.close()
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     # ------------------------------------------------------------------ single GPU

@@ -82,12 +82,18 @@ class GpuSlabCompute:
         nbytes = E.FluidEngine.required_arena_bytes(params, 0, slab=slab)
         if nbytes == 0:
             raise RuntimeError("invalid slab geometry")
+        # One explicit side stream, made torch's current stream for this process: the engine's
+        # kernels and the communicator's stream-ordering both follow it.  (The legacy null stream
+        # has handle 0, which the C ABI reads as "create your own".)
+        self.stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(self.stream)
         self.arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         base = self.arena.data_ptr()
         self._pad = (-base) % 256
+        assert self.stream.cuda_stream != 0
         self.engine = E.FluidEngine(
             params, particle_capacity=0, device=device.index if device.index is not None else -1,
-            slab=slab, stream=torch.cuda.current_stream(device).cuda_stream,
+            slab=slab, stream=self.stream.cuda_stream,
             arena=base + self._pad, arena_bytes=nbytes)
         self.engine.set_option(E.OPT_PRESSURE_KERNEL, pressure_kernel)
         self._base = base
@@ -172,7 +178,12 @@ class HostSlabCompute:
 
 # ---- the solver ------------------------------------------------------------------------------------------
 class SlabPressureSolver:
-    def __init__(self, size, iterations: int, ctx: DistContext, compute, slab: Tuple[int, int]):
+    def __init__(self, size, iterations: int, ctx: DistContext, compute, slab: Tuple[int, int],
+                 transport: str = "direct"):
+        # transport "direct": the communicator addresses the planes where they live (RCCL on
+        # device memory, gloo on host memory).  "staged": bounce through host tensors — only for
+        # rehearsing the GPU slab path over gloo on a box with a single GPU (tests).
+        self.transport = transport
         self.size = tuple(size)
         self.iterations = iterations
         self.ctx = ctx
@@ -180,7 +191,8 @@ class SlabPressureSolver:
         self.z_begin, self.z_count = slab
         self.lo = ctx.rank - 1 if ctx.rank > 0 else None
         self.hi = ctx.rank + 1 if ctx.rank < ctx.world - 1 else None
-        self.exchange_seconds = 0.0
+        self._plans = {}
+        self._ops = {}
 
     @classmethod
     def create_gpu(cls, size, iterations: int, ctx: DistContext, pressure_kernel: int = 0,
@@ -208,16 +220,40 @@ class SlabPressureSolver:
 
         if self.ctx.world == 1:
             return
-        ops = []
-        c = self.compute
-        if self.lo is not None:
-            ops.append(dist.P2POp(dist.isend, c.plane(image_id, 0), self.lo))
-            ops.append(dist.P2POp(dist.irecv, c.plane(image_id, -1), self.lo))
-        if self.hi is not None:
-            ops.append(dist.P2POp(dist.isend, c.plane(image_id, self.z_count - 1), self.hi))
-            ops.append(dist.P2POp(dist.irecv, c.plane(image_id, self.z_count), self.hi))
+        plan = self._plan(image_id)
+        if self.transport == "staged":
+            staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
+                      for snd, t, peer in plan]
+            ops = [dist.P2POp(dist.isend if snd else dist.irecv, h, peer)
+                   for snd, h, _, peer in staged]
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+            for snd, h, t, _ in staged:
+                if not snd:
+                    t.copy_(h)
+            return
+        ops = self._ops.get(image_id)
+        if ops is None:
+            ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer) for snd, t, peer in plan]
+            self._ops[image_id] = ops
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+
+    def _plan(self, image_id: int):
+        """(is_send, plane tensor, peer) for this image — tensor views are built once and reused
+        (the planes never move)."""
+        plan = self._plans.get(image_id)
+        if plan is None:
+            c = self.compute
+            plan = []
+            if self.lo is not None:
+                plan.append((True, c.plane(image_id, 0), self.lo))
+                plan.append((False, c.plane(image_id, -1), self.lo))
+            if self.hi is not None:
+                plan.append((True, c.plane(image_id, self.z_count - 1), self.hi))
+                plan.append((False, c.plane(image_id, self.z_count), self.hi))
+            self._plans[image_id] = plan
+        return plan
 
     # -- the loop section ---------------------------------------------------------------------------------
     def clear_pressures(self):
