@@ -242,6 +242,12 @@ int fluid_run_section(fluid_ctx* ctx, int section_id);
  * SURVEY.md F2).  Only FLUID_SEC_12_SOLVE_PRESSURE is a loop section on this path. */
 int fluid_run_section_loop(fluid_ctx* ctx, int section_id, uint32_t iterations);
 
+/* FlowClearColorSection(ctx, image, ClearValue) for an arbitrary image and value
+ * (fluid_flow_sections.h:140-142,163,298-299 are the uses on this path).  `value_bits` holds the
+ * texel as 32-bit patterns: 4 words for RGBA32F, 1 for R32F / R32_UINT, the low byte of word 0 for
+ * R8_UINT.  Clearing PRESSURES_1/2 also resets the 12_solve_pressure loop counter. */
+int fluid_clear_image(fluid_ctx* ctx, int image_id, const uint32_t value_bits[4]);
+
 /* One 12_solve_pressure dispatch with an explicit push constant (pressure.comp:29-31). */
 int fluid_run_pressure_dispatch(fluid_ctx* ctx, uint32_t is_even_iteration);
 

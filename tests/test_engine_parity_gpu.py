@@ -290,3 +290,43 @@ def test_timing_counts_sections():
         assert times["00_init_particles"][1] == 1
         eng.reset_timing()
         assert eng.section_time_ms("07_advect") == (0.0, 0)
+
+
+def test_cpp_section_list_driver_matches_oracle(tmp_path):
+    """The C++ host mirror of the reference's section lists (include/fluid_flow_sections_amd.hpp)
+    driven in main.cpp's call order by host/fluid_sim: init list once, step list per frame."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "vulkan-3d-fluid-simulation_amd", "host", "fluid_sim")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    size, frames, iters = (32, 32, 32), 2, 10
+    res = subprocess.run([exe, *map(str, size), str(frames), str(iters), str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "17 sections" in res.stdout  # SimulationStepSections 01a…14
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters)
+    st.run_init()
+    for _ in range(frames):
+        st.run_step()
+    for name, dtype in [("velocities_1", np.float32), ("cell_types", np.uint8),
+                        ("pressures_1", np.float32), ("pressures_2", np.float32),
+                        ("particles", np.float32)]:
+        got = np.fromfile(os.path.join(str(tmp_path), name + ".bin"), dtype=dtype)
+        assert_bit_equal(got.reshape(getattr(st, name).shape), getattr(st, name), f"C++ {name}")
+
+
+def test_clear_image_arbitrary_value():
+    st = random_state((24, 20, 16), seed=2)
+    with make_engine(st) as eng:
+        eng.clear_image(E.VELOCITIES_2, (1.5, -2.0, 0.25, 9.0))
+        eng.clear_image(E.NEW_CELL_TYPES, 3)
+        eng.clear_image(E.DIVERGENCES, -0.75)
+        eng.clear_image(E.PARTICLE_DENSITIES_IMG, 41)
+        st.velocities_2[...] = (1.5, -2.0, 0.25, 9.0)
+        st.new_cell_types[...] = 3
+        st.divergences[...] = -0.75
+        st.particle_densities[...] = 41
+        assert_state_equal(eng, st)

@@ -255,32 +255,38 @@ struct SectionTimer {
 };
 
 // ---- fills -------------------------------------------------------------------------------------
-// Fill the OWNED planes of an image with a repeated 32-bit (or 8-bit) pattern.
-int fill_image(fluid_ctx* c, int image, uint32_t pattern32) {
-    const uint64_t bytes = c->owned_cells() * c->img[image].elem_bytes;
+// Fill the OWNED planes of an image with one texel value (FlowClearColorSection).  `v` holds the
+// texel as 32-bit words: 4 for RGBA32F, 1 for R32*, low byte of v[0] for R8.
+int fill_image4(fluid_ctx* c, int image, const uint32_t v[4]) {
+    const uint32_t eb = c->img[image].elem_bytes;
+    const uint64_t bytes = c->owned_cells() * eb;
     uint8_t* dst = c->plane0<uint8_t>(image);
-    // plane0 is 16-byte aligned when plane*elem is; W*H*elem may not be a multiple of 16 for tiny
-    // odd grids, so split into an aligned vector body and byte tails.
+    uint4 pat;
+    if (eb == 16)
+        pat = make_uint4(v[0], v[1], v[2], v[3]);
+    else if (eb == 4)
+        pat = make_uint4(v[0], v[0], v[0], v[0]);
+    else {
+        const uint32_t b = (v[0] & 0xFFu) * 0x01010101u;
+        pat = make_uint4(b, b, b, b);
+    }
+    // plane 0 is 16-byte aligned whenever W*H*elem is; tiny odd grids need byte/word head + tail
     const uint64_t addr = reinterpret_cast<uint64_t>(dst);
     const uint64_t head = std::min<uint64_t>(bytes, (16 - (addr & 15)) & 15);
     const uint64_t body = (bytes - head) / 16;
     const uint64_t tail_begin = head + body * 16;
-    if (c->img[image].elem_bytes == 1) pattern32 = (pattern32 & 0xFFu) * 0x01010101u;
-    if (head % c->img[image].elem_bytes != 0)
-        return c->fail(FLUID_ERR_UNSUPPORTED, "image base not element-aligned");
+    if (head % eb != 0) return c->fail(FLUID_ERR_UNSUPPORTED, "image base not element-aligned");
     if (body > 0) {
         const int blocks = (int)std::min<uint64_t>((body + 255) / 256, 256 * 8);
         hipLaunchKernelGGL(k_fill_u32x4, dim3(blocks), dim3(256), 0, c->stream,
-                           reinterpret_cast<uint4*>(dst + head), (int64_t)body,
-                           make_uint4(pattern32, pattern32, pattern32, pattern32));
+                           reinterpret_cast<uint4*>(dst + head), (int64_t)body, pat);
     }
-    // head/tail (< 16 bytes each): memsets of the pattern
-    auto small = [&](uint64_t b, uint64_t e) -> int {
+    auto small = [&](uint64_t b, uint64_t e) -> int {  // < 16 bytes, never RGBA32F
         if (e <= b) return FLUID_OK;
-        if (c->img[image].elem_bytes == 1) {
-            HIP_TRY(c, hipMemsetAsync(dst + b, (int)(pattern32 & 0xFF), e - b, c->stream));
+        if (eb == 1) {
+            HIP_TRY(c, hipMemsetAsync(dst + b, (int)(pat.x & 0xFF), e - b, c->stream));
         } else {
-            HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst + b), (int)pattern32,
+            HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst + b), (int)pat.x,
                                          (e - b) / 4, c->stream));
         }
         return FLUID_OK;
@@ -291,6 +297,10 @@ int fill_image(fluid_ctx* c, int image, uint32_t pattern32) {
     if (rc) return rc;
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
+}
+int fill_image(fluid_ctx* c, int image, uint32_t pattern32) {
+    const uint32_t v[4] = {pattern32, pattern32, pattern32, pattern32};
+    return fill_image4(c, image, v);
 }
 
 uint32_t f32_bits(float f) {
@@ -792,6 +802,17 @@ int fluid_run_section(fluid_ctx* c, int section_id) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     return timed_section(c, section_id);
+}
+
+int fluid_clear_image(fluid_ctx* c, int image_id, const uint32_t value_bits[4]) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    if (!value_bits) return c->fail(FLUID_ERR_INVALID_ARG, "null clear value");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2)
+        c->pressure_dispatch_index = 0;
+    return fill_image4(c, image_id, value_bits);
 }
 
 int fluid_run_pressure_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {

@@ -56,7 +56,8 @@ EXPORTED_SYMBOLS = [
     "fluid_destroy", "fluid_last_error", "fluid_upload_image", "fluid_download_image",
     "fluid_upload_buffer", "fluid_download_buffer", "fluid_image_bytes", "fluid_buffer_bytes",
     "fluid_set_params", "fluid_set_pressure_iterations", "fluid_set_diffuse_mode",
-    "fluid_run_section", "fluid_run_section_loop", "fluid_run_pressure_dispatch", "fluid_run_init",
+    "fluid_run_section", "fluid_run_section_loop", "fluid_clear_image",
+    "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_get_geometry", "fluid_set_option",
 ]
@@ -117,6 +118,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_set_diffuse_mode": (C.c_int, [vp, C.c_int]),
         "fluid_run_section": (C.c_int, [vp, C.c_int]),
         "fluid_run_section_loop": (C.c_int, [vp, C.c_int, u32]),
+        "fluid_clear_image": (C.c_int, [vp, C.c_int, C.POINTER(u32 * 4)]),
         "fluid_run_pressure_dispatch": (C.c_int, [vp, u32]),
         "fluid_run_init": (C.c_int, [vp]),
         "fluid_run_step": (C.c_int, [vp]),
@@ -278,6 +280,15 @@ class FluidEngine:
     def solve_pressure(self, iterations: int):
         """The 12_solve_pressure loop section (fluid_flow_sections.h:300-313)."""
         self.run_section_loop(SEC_12_SOLVE_PRESSURE, iterations)
+
+    def clear_image(self, image_id: int, value):
+        """FlowClearColorSection: `value` is a scalar or 4-tuple in the image's own type."""
+        dtype, ch = IMAGE_DTYPES.get(image_id, (np.uint32, 1))
+        vals = np.zeros(4, dtype=np.float32 if dtype == np.float32 else np.uint32)
+        v = np.atleast_1d(np.asarray(value))
+        vals[:len(v)] = v.astype(vals.dtype)
+        bits = (C.c_uint32 * 4)(*[int(x) for x in vals.view(np.uint32)])
+        self._check(self._lib.fluid_clear_image(self._h, image_id, C.byref(bits)))
 
     def run_pressure_dispatch(self, is_even_iteration: int):
         self._check(self._lib.fluid_run_pressure_dispatch(self._h, is_even_iteration))
