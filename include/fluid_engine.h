@@ -272,13 +272,19 @@ int fluid_reset_timing(fluid_ctx* ctx);
  * 0 … z_count-1 = owned planes, z_count = upper ghost plane.  Planes are contiguous in memory.    */
 int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** device_ptr,
                           uint64_t* bytes);
+/* Tell the engine that the caller wrote device memory of `image_id` through a pointer obtained
+ * from fluid_image_plane_ptr (halo exchange), so data the engine derives from it is rebuilt.
+ * Ghost planes of PRESSURES_1/2 must carry the neighbouring slab's cells of the same buffer. */
+int fluid_notify_image_written(fluid_ctx* ctx, int image_id);
 /* Geometry of this context. */
 int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* slab_z_begin,
                        uint32_t* slab_z_count, uint64_t* particle_capacity);
 
 /* ---- engine options (performance variants of the same arithmetic; results are bit-identical) -- */
 typedef enum fluid_option {
-    FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto, 1 = plain one-cell-per-thread, 2 = z-marching tile   */
+    FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto; 1 = one cell per thread; 2/3/4 = z-marching, 2/4/1   */
+                                   /* rows per wavefront; 5/6/7 = canonical-state fast path, 2/4/1   */
+                                   /* rows (falls back to 2 when the pressures are not canonical)    */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

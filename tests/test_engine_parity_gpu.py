@@ -206,7 +206,7 @@ def test_pressure_256cubed_variants_agree_and_window_matches_oracle():
     t = scenes.full_fluid_types(shape)
     div = scenes.full_fluid_divergence(shape)
     results = {}
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 5, 6, 7):
         with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
             eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
             eng.upload_image(E.CELL_TYPES, t)
@@ -215,7 +215,7 @@ def test_pressure_256cubed_variants_agree_and_window_matches_oracle():
             eng.run_section("12b_clear_pressures_2")
             eng.solve_pressure(iters)
             results[variant] = (eng.download_image(E.PRESSURES_1), eng.download_image(E.PRESSURES_2))
-    for variant in (2, 3):
+    for variant in (2, 3, 5, 6, 7):
         assert_bit_equal(results[variant][0], results[1][0], f"P1 variant {variant} vs plain")
         assert_bit_equal(results[variant][1], results[1][1], f"P2 variant {variant} vs plain")
     z0, zc = 100, 24
@@ -330,3 +330,117 @@ def test_clear_image_arbitrary_value():
         st.divergences[...] = -0.75
         st.particle_densities[...] = 41
         assert_state_equal(eng, st)
+
+
+# ---- the canonical-state fast path of 12_solve_pressure (kernels_pressure.h: k12_canon) -----------------
+@pytest.mark.parametrize("variant", [0, 5, 6, 7])
+@pytest.mark.parametrize("size", [(24, 20, 16), (64, 64, 64), (260, 12, 9), (512, 7, 3), (256, 16, 8)])
+@pytest.mark.parametrize("iters", [1, 2, 9])
+def test_pressure_canonical_path_matches_oracle(variant, size, iters):
+    """After the two clears both pressure images are canonical (every non-water cell holds p_air)
+    and the loop runs the mask-based kernel; random types (all four kinds, no solid shell) and
+    random divergences."""
+    st = random_state(size, seed=3 * iters + variant, solid_walls=(variant % 2 == 0))
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+        for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
+            eng.run_section(name)
+            st.run_section(name)
+        eng.solve_pressure(iters)
+        st.solve_pressure(iters)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"],
+                           ctx=f"canon x{iters} variant {variant} {size}: ")
+        # the loop can be continued, and single dispatches interleave with it
+        eng.run_pressure_dispatch(1)
+        st.pressure_dispatch(1)
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="continued: ")
+
+
+def test_pressure_fast_path_invalidation():
+    """Everything that can make the cached mask / b_i / canonical flags stale."""
+    size = (64, 24, 12)
+    st = random_state(size, seed=77, solid_walls=False)
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_PRESSURE_KERNEL, 5)
+
+        def clears():
+            for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
+                eng.run_section(name)
+                st.run_section(name)
+
+        def check(ctx):
+            assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx=ctx + ": ")
+
+        clears()
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("baseline")
+        # new divergence: b_i must be rebuilt
+        st.divergences[...] = np.random.default_rng(1).uniform(-1, 1, st.shape).astype(np.float32)
+        eng.upload_image(E.DIVERGENCES, st.divergences)
+        clears()
+        eng.solve_pressure(2)
+        st.solve_pressure(2)
+        check("new divergence")
+        # new cell types while the pressures hold sweep results: no longer canonical -> general path
+        rng = np.random.default_rng(2)
+        st.cell_types[...] = rng.integers(0, 4, st.shape).astype(np.uint8)
+        eng.upload_image(E.CELL_TYPES, st.cell_types)
+        eng.solve_pressure(2)
+        st.solve_pressure(2)
+        check("types changed, stale pressures")
+        clears()
+        eng.solve_pressure(4)
+        st.solve_pressure(4)
+        check("types changed, after clears")
+        # uploaded pressures are not canonical
+        st.pressures_1[...] = rng.uniform(0, 2, st.shape).astype(np.float32)
+        eng.upload_image(E.PRESSURES_1, st.pressures_1)
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("uploaded P1")
+        # clear_image with p_air is as good as the section; with another value it is not
+        eng.clear_image(E.PRESSURES_1, 1.0)
+        eng.clear_image(E.PRESSURES_2, 1.0)
+        st.pressures_1[...] = 1.0
+        st.pressures_2[...] = 1.0
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("clear_image p_air")
+        eng.clear_image(E.PRESSURES_1, 0.5)
+        st.pressures_1[...] = 0.5
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("clear_image 0.5")
+        # parameters: p_air, dt, rho, dx and a permutation of the type values
+        p2 = st.params.copy()
+        p2.pressure_air, p2.time_delta, p2.fluid_density, p2.cell_width = 0.75, 0.02, 1.5, 0.5
+        p2.cell_type_inactive, p2.cell_type_air, p2.cell_type_water, p2.cell_type_solid = 3, 2, 1, 0
+        eng.set_params(p2)
+        st.params = p2
+        st._p = __import__("ctypes").byref(st.params)
+        clears()
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("new params (solid == 0: fast path must refuse)")
+        p3 = p2.copy()
+        p3.cell_type_solid, p3.cell_type_inactive = 9, 0
+        st.cell_types[st.cell_types == 0] = 9
+        eng.upload_image(E.CELL_TYPES, st.cell_types)
+        eng.set_params(p3)
+        st.params = p3
+        st._p = __import__("ctypes").byref(st.params)
+        clears()
+        eng.solve_pressure(3)
+        st.solve_pressure(3)
+        check("new params (solid == 9)")
+        # the divergence section itself invalidates b_i
+        eng.upload_image(E.VELOCITIES_1, st.velocities_1)
+        eng.run_section("11_compute_divergence")
+        st.run_section("11_compute_divergence")
+        clears()
+        eng.solve_pressure(2)
+        st.solve_pressure(2)
+        check("after section 11")

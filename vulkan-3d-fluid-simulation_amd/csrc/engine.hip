@@ -79,6 +79,12 @@ struct fluid_ctx {
     ImageDesc img[8];
     int64_t opt[FLUID_OPT_COUNT] = {0};
 
+    // canonical-state fast path of 12_solve_pressure (kernels_pressure.h: k12_prepare / k12_canon)
+    uint64_t mask_offset = 0, rhs_offset = 0;  // internal per-cell byte mask / b_i, (Dl+2) planes
+    bool mask_valid = false;   // mask matches CELL_TYPES and the cell type values
+    bool rhs_valid = false;    // b_i matches DIVERGENCES and rho, dx, dt
+    bool p_canon[2] = {false, false};  // every non-water cell of PRESSURES_1/2 holds p_air
+
     bool timing = false;
     std::vector<TimerSlot> pending;
     std::vector<TimerSlot> free_slots;
@@ -102,6 +108,28 @@ struct fluid_ctx {
                                     (uint64_t)g.plane * img[image].elem_bytes);
     }
     float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
+    uint8_t* mask0() const { return arena + mask_offset + (uint64_t)g.plane; }
+    float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + g.plane; }
+    // bookkeeping for the fast path: call whenever an image's device contents change
+    void touched(int image) {
+        switch (image) {
+            case FLUID_IMG_CELL_TYPES:
+                mask_valid = false;
+                p_canon[0] = p_canon[1] = false;
+                break;
+            case FLUID_IMG_DIVERGENCES:
+                rhs_valid = false;
+                break;
+            case FLUID_IMG_PRESSURES_1:
+                p_canon[0] = false;
+                break;
+            case FLUID_IMG_PRESSURES_2:
+                p_canon[1] = false;
+                break;
+            default:
+                break;
+        }
+    }
     uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
 };
 
@@ -176,6 +204,7 @@ ParamsK make_params_k(const fluid_params& p) {
 struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
+    uint64_t mask_offset, rhs_offset;
     uint64_t total;
 };
 
@@ -201,6 +230,10 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     L.particles_offset = off;
     L.particles_bytes = capacity * 16;
     off = align_up(off + L.particles_bytes, kAlign);
+    L.mask_offset = off;
+    off = align_up(off + plane * (uint64_t)(dl + 2), kAlign);
+    L.rhs_offset = off;
+    off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
 }
@@ -320,19 +353,46 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     const uint8_t* t = c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES);
     const float* div = c->plane0<float>(FLUID_IMG_DIVERGENCES);
     int64_t variant = c->opt[FLUID_OPT_PRESSURE_KERNEL];
-    const bool zmarch_ok = (g.W % 4 == 0);
-    if (variant == 0) variant = (zmarch_ok && g.W >= 64) ? 2 : 1;
-    if (variant >= 2 && !zmarch_ok) variant = 1;
+    const bool vec_ok = (g.W % 4 == 0);
+    // The fast path needs both buffers canonical and "type 0" (an out-of-bounds load) to be neither
+    // solid nor water.
+    const bool canon_ok = vec_ok && c->p_canon[0] && c->p_canon[1] && c->pk.t_solid != 0 &&
+                          c->pk.t_water != 0;
+    if (variant == 0) variant = canon_ok ? 5 : ((vec_ok && g.W >= 64) ? 2 : 1);
+    if (variant >= 5 && !canon_ok) variant = vec_ok ? 2 : 1;
+    if (variant >= 2 && !vec_ok) variant = 1;
     if (variant == 1) {
         hipLaunchKernelGGL(k12_plain, cell_grid(g), cell_block(), 0, c->stream, t, div, pin, pout, g,
                            c->pk);
+        HIP_TRY(c, hipGetLastError());
+        return FLUID_OK;
+    }
+    // rows per wavefront: variants 2/5 -> 2, 3/6 -> 4, 4/7 -> 1
+    const int ry = (variant == 3 || variant == 6) ? 4 : ((variant == 4 || variant == 7) ? 1 : 2);
+    const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
+    // pick the z chunk so the launch has a few thousand workgroups (>> 256 CUs)
+    int zchunk = g.Dl;
+    while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048) zchunk /= 2;
+    const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
+    if (variant >= 5) {
+        if (!c->mask_valid || !c->rhs_valid) {
+            hipLaunchKernelGGL(k12_prepare, cell_grid(g), cell_block(), 0, c->stream, t, div,
+                               c->mask0(), c->rhs0(), g, c->pk, c->mask_valid ? 0 : 1,
+                               c->rhs_valid ? 0 : 1);
+            c->mask_valid = c->rhs_valid = true;
+        }
+        const uint8_t* m = c->mask0();
+        const float* b = c->rhs0();
+        if (ry == 4)
+            hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
+                               c->pk.p_air, zchunk);
+        else if (ry == 1)
+            hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
+                               c->pk.p_air, zchunk);
+        else
+            hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
+                               c->pk.p_air, zchunk);
     } else {
-        // pick the z chunk so the launch has a few thousand workgroups (>> 256 CUs)
-        const int ry = variant == 3 ? 4 : (variant == 4 ? 1 : 2);
-        const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
-        int zchunk = g.Dl;
-        while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048) zchunk /= 2;
-        const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
         if (ry == 4)
             hipLaunchKernelGGL(k12_zmarch<4>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
                                c->pk, zchunk);
@@ -370,6 +430,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
             return fill_image(c, FLUID_IMG_VELOCITIES_1, 0u);
         case FLUID_SEC_INIT_CLEAR_CELL_TYPES:
+            c->touched(FLUID_IMG_CELL_TYPES);
             return fill_image(c, FLUID_IMG_CELL_TYPES, pk.t_inactive);
         case FLUID_SEC_00_INIT_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
@@ -400,6 +461,7 @@ int run_section_impl(fluid_ctx* c, int section) {
                                pk);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
+            c->touched(FLUID_IMG_CELL_TYPES);
             HIP_TRY(c, hipMemcpyAsync(T, newT, c->owned_cells(), hipMemcpyDeviceToDevice,
                                       c->stream));
             return FLUID_OK;
@@ -420,14 +482,17 @@ int run_section_impl(fluid_ctx* c, int section) {
             hipLaunchKernelGGL(k10_solids, grid, block, 0, c->stream, T, V1, g, pk);
             break;
         case FLUID_SEC_11_COMPUTE_DIVERGENCE:
+            c->touched(FLUID_IMG_DIVERGENCES);
             hipLaunchKernelGGL(k11_divergence, grid, block, 0, c->stream, V1,
                                c->plane0<float>(FLUID_IMG_DIVERGENCES), g);
             break;
         case FLUID_SEC_12A_CLEAR_PRESSURES_1:
             c->pressure_dispatch_index = 0;
+            c->p_canon[0] = true;  // every cell holds p_air
             return fill_image(c, FLUID_IMG_PRESSURES_1, f32_bits(pk.p_air));
         case FLUID_SEC_12B_CLEAR_PRESSURES_2:
             c->pressure_dispatch_index = 0;
+            c->p_canon[1] = true;
             return fill_image(c, FLUID_IMG_PRESSURES_2, f32_bits(pk.p_air));
         case FLUID_SEC_12_SOLVE_PRESSURE: {
             const uint32_t even = (c->pressure_dispatch_index % 2u) == 0u ? 1u : 0u;
@@ -610,6 +675,8 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
         c->img[i].bytes = L.img_bytes[i];
     }
     c->particles_offset = L.particles_offset;
+    c->mask_offset = L.mask_offset;
+    c->rhs_offset = L.rhs_offset;
     c->arena_bytes = L.total;
 
     auto bail = [&](int code, const std::string& msg) {
@@ -699,6 +766,7 @@ int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t by
         return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
                        image_id, (unsigned long long)want, (unsigned long long)bytes);
     HIP_TRY(c, hipSetDevice(c->device));
+    c->touched(image_id);
     HIP_TRY(c, hipMemcpyAsync(c->plane0<uint8_t>(image_id), host, bytes, hipMemcpyHostToDevice,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -734,6 +802,8 @@ int fluid_set_params(fluid_ctx* c, const void* blob) {
             return c->fail(FLUID_ERR_SIZE_MISMATCH, "fluid_size cannot change on a live context");
     c->params = p;
     c->pk = make_params_k(p);
+    c->mask_valid = c->rhs_valid = false;  // cell type values, rho, dx, dt, p_air may have changed
+    c->p_canon[0] = c->p_canon[1] = false;
     return FLUID_OK;
 }
 
@@ -810,8 +880,11 @@ int fluid_clear_image(fluid_ctx* c, int image_id, const uint32_t value_bits[4]) 
     if (rc) return rc;
     if (!value_bits) return c->fail(FLUID_ERR_INVALID_ARG, "null clear value");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2)
+    c->touched(image_id);
+    if (image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2) {
         c->pressure_dispatch_index = 0;
+        c->p_canon[image_id - FLUID_IMG_PRESSURES_1] = value_bits[0] == f32_bits(c->pk.p_air);
+    }
     return fill_image4(c, image_id, value_bits);
 }
 
@@ -929,6 +1002,17 @@ int fluid_image_plane_ptr(fluid_ctx* c, int image_id, int32_t plane, void** devi
     const uint64_t pb = (uint64_t)c->g.plane * c->img[image_id].elem_bytes;
     *device_ptr = c->arena + c->img[image_id].offset + (uint64_t)(plane + 1) * pb;
     *bytes = pb;
+    return FLUID_OK;
+}
+
+int fluid_notify_image_written(fluid_ctx* c, int image_id) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    // Halo planes of the pressures arrive from the neighbouring slab in the neighbour's (canonical
+    // or not) state, which is this slab's state too: only derived data is invalidated.
+    if (image_id == FLUID_IMG_CELL_TYPES) c->mask_valid = false;
+    if (image_id == FLUID_IMG_DIVERGENCES) c->rhs_valid = false;
     return FLUID_OK;
 }
 

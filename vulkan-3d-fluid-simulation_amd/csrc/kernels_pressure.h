@@ -230,4 +230,233 @@ k12_zmarch(const uint8_t* __restrict__ t, const float* __restrict__ div,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The canonical-state fast path.
+//
+// Observation (pressure.comp:41-50,69): a sweep never writes a non-water cell, and for a non-solid
+// non-water neighbour it subtracts p_air instead of reading Pin.  After the clears of
+// fluid_flow_sections.h:298-299 every non-water cell of PRESSURES_1/2 HOLDS p_air and keeps it for
+// the whole loop ("canonical" buffers; the engine tracks this, see engine.hip).  Then
+//     (t == water ? Pin[n] : p_air)  ==  Pin[n]        for every non-solid neighbour n,
+// so a sweep needs, per cell, only: is the cell water, which of its 6 neighbours are non-solid
+// (7 bits), Pin, and the sweep-invariant b_i = ((div*rho)*dx)/dt.  k12_prepare packs the 7 bits
+// into one byte per cell and evaluates b_i once per loop; k12_canon then moves exactly the
+// algorithmic 13 B/cell (mask 1 + b 4 + Pin 4 + Pout 4) with no type-neighbourhood traffic, and
+// stores Pin's own value for non-water cells (== what Pout already holds), which keeps every store
+// a full 16-byte vector.  Arithmetic per water cell is the shader's, in the shader's order:
+//     s = b_i;  for n in +x,+y,+z,-x,-y,-z: if non-solid: s -= Pin[n], aii++;  Pout = -s/aii
+// Out-of-bounds neighbours are non-solid with pressure p_air (type 0, pressure.comp:43-47).
+
+// bit j (0..5) = neighbour j (+x,+y,+z,-x,-y,-z) is not SOLID; bit 6 = cell is WATER
+__global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restrict__ div,
+                            uint8_t* __restrict__ mask, float* __restrict__ rhs, GridK g,
+                            ParamsK p, int do_mask, int do_rhs) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    if (do_rhs) rhs[id] = ((div[id] * p.rho) * p.dx) / p.dt;  // pressure.comp:54
+    if (do_mask) {
+        uint32_t m = 0;
+        m |= (type_at(t, g, x + 1, y, lz) != p.t_solid) ? 1u : 0u;
+        m |= (type_at(t, g, x, y + 1, lz) != p.t_solid) ? 2u : 0u;
+        m |= ((uint32_t)t[cidx(g, x, y, lz + 1)] != p.t_solid) ? 4u : 0u;
+        m |= (type_at(t, g, x - 1, y, lz) != p.t_solid) ? 8u : 0u;
+        m |= (type_at(t, g, x, y - 1, lz) != p.t_solid) ? 16u : 0u;
+        m |= ((uint32_t)t[cidx(g, x, y, lz - 1)] != p.t_solid) ? 32u : 0u;
+        m |= ((uint32_t)t[id] == p.t_water) ? 64u : 0u;
+        mask[id] = (uint8_t)m;
+    }
+}
+
+// lane i <- lane i-1 / lane i+1 across the whole wavefront (DPP wave_shr:1 / wave_shl:1);
+// lanes 0 / 63 receive `edge`.
+__device__ __forceinline__ float from_lane_below(float v, float edge, int lane) {
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false);
+    return lane == 0 ? edge : __int_as_float(r);
+}
+__device__ __forceinline__ float from_lane_above(float v, float edge, int lane) {
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false);
+    return lane == 63 ? edge : __int_as_float(r);
+}
+
+// one water cell; m6 = its mask byte; q* = Pin of the six neighbours
+__device__ __forceinline__ float canon_cell(float b, uint32_t m, int sh, float qxp, float qyp,
+                                            float qzp, float qxm, float qym, float qzm) {
+    // (bit ? q : +0.0f): s - 0.0f == s bit for bit, so the conditional subtraction of the shader
+    // becomes an AND with a sign-extended bit
+    auto pick = [&](float q, int j) -> float {
+        const int ext = __builtin_amdgcn_sbfe(m, sh + j, 1);  // 0 or -1
+        return __int_as_float(__float_as_int(q) & ext);
+    };
+    float s = b;
+    s = s - pick(qxp, 0);
+    s = s - pick(qyp, 1);
+    s = s - pick(qzp, 2);
+    s = s - pick(qxm, 3);
+    s = s - pick(qym, 4);
+    s = s - pick(qzm, 5);
+    const float aii = (float)__builtin_popcount((m >> sh) & 63u);
+    return -s / aii;
+}
+
+template <int RY>
+struct CanonAux {       // per-plane data that is only needed for the plane being computed
+    float4 b[RY];       // b_i of the wave's own rows
+    uint32_t m[RY];     // masks, 4 cells per word
+    float4 hl, hh;      // Pin halo rows y0-1 / y0+RY
+    float e;            // Pin of the cells just outside the wave's x range (per-lane encoding)
+};
+
+template <int RY>
+struct CanonGeom {
+    unsigned boff[RY];  // in-plane BYTE offsets of the own rows in an R32F image (32-bit: a plane
+                        // is far below 4 GiB; keeps every access base(SGPR)+offset(VGPR))
+    unsigned boff_lo, boff_hi, boff_e;
+    bool rok[RY], lo_ok, hi_ok, e_ok, face_lo, face_hi;
+    int lane;
+    float p_air;
+};
+
+__device__ __forceinline__ float4 ld_f4(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+template <int RY>
+__device__ __forceinline__ void canon_load_own(const CanonGeom<RY>& q, const float* pin,
+                                               const GridK& g, int lz, float4* dst) {
+    const float* pp = pin + (int64_t)lz * g.plane;  // wave-uniform
+    const bool oob_z = (lz < 0 && q.face_lo) || (lz >= g.Dl && q.face_hi);
+    const float4 pa4 = make_float4(q.p_air, q.p_air, q.p_air, q.p_air);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const float4 v = ld_f4(pp, q.boff[r]);
+        dst[r] = (q.rok[r] && !oob_z) ? v : pa4;
+    }
+}
+
+template <int RY>
+__device__ __forceinline__ void canon_load_aux(const CanonGeom<RY>& q, const uint8_t* mask,
+                                               const float* rhs, const float* pin, const GridK& g,
+                                               int lz, CanonAux<RY>& a) {
+    const float* pp = pin + (int64_t)lz * g.plane;
+    const float* rr = rhs + (int64_t)lz * g.plane;
+    const uint8_t* mm = mask + (int64_t)lz * g.plane;
+    const float4 pa4 = make_float4(q.p_air, q.p_air, q.p_air, q.p_air);
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        a.b[r] = ld_f4(rr, q.boff[r]);
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(mm + (q.boff[r] >> 2));
+        a.m[r] = q.rok[r] ? m : 0u;  // outside the grid: not water, nothing computed or stored
+    }
+    const float4 lo = ld_f4(pp, q.boff_lo), hi = ld_f4(pp, q.boff_hi);
+    a.hl = q.lo_ok ? lo : pa4;
+    a.hh = q.hi_ok ? hi : pa4;
+    const float ev = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pp) + q.boff_e);
+    a.e = q.e_ok ? ev : q.p_air;
+}
+
+// One plane: issue the loads of the next step (own rows of plane lz+2 into `pnn`, everything else
+// of plane lz+1 into `an`), then compute plane lz from (pm, pc, pn, ac) and store it.
+template <int RY>
+__device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t* mask,
+                                           const float* rhs, const float* pin, float* pout,
+                                           const GridK& g, int lz, int ze, const float4* pm,
+                                           const float4* pc, const float4* pn, float4* pnn,
+                                           const CanonAux<RY>& ac, CanonAux<RY>& an) {
+    if (lz + 1 < ze) {  // wave-uniform
+        canon_load_own<RY>(q, pin, g, lz + 2, pnn);
+        canon_load_aux<RY>(q, mask, rhs, pin, g, lz + 1, an);
+    }
+    float* po = pout + (int64_t)lz * g.plane;
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        const float4 c = pc[r];
+        const float el = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ac.e), 2 * r));
+        const float er = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ac.e), 2 * r + 1));
+        const float left = from_lane_below(c.w, el, q.lane);
+        const float right = from_lane_above(c.x, er, q.lane);
+        const float4 ym = r == 0 ? ac.hl : pc[r == 0 ? 0 : r - 1];
+        const float4 yp = r == RY - 1 ? ac.hh : pc[r == RY - 1 ? r : r + 1];
+        const float4 zm = pm[r], zp = pn[r];
+        const float4 b = ac.b[r];
+        const uint32_t m = ac.m[r];
+        float4 o;
+        o.x = canon_cell(b.x, m, 0, c.y, yp.x, zp.x, left, ym.x, zm.x);
+        o.y = canon_cell(b.y, m, 8, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
+        o.z = canon_cell(b.z, m, 16, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
+        o.w = canon_cell(b.w, m, 24, right, yp.w, zp.w, c.z, ym.w, zm.w);
+        // non-water cells keep their value: Pout already equals Pin there (both canonical)
+        o.x = (m & 0x40u) ? o.x : c.x;
+        o.y = (m & 0x4000u) ? o.y : c.y;
+        o.z = (m & 0x400000u) ? o.z : c.z;
+        o.w = (m & 0x40000000u) ? o.w : c.w;
+        if (q.rok[r])
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(po) + q.boff[r]) = o;
+    }
+}
+
+template <int RY>
+__global__ void __launch_bounds__(256)
+k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
+          const float* __restrict__ pin, float* __restrict__ pout, GridK g, float p_air,
+          int zchunk) {
+    CanonGeom<RY> q;
+    q.lane = threadIdx.x & 63;
+    q.p_air = p_air;
+    const int wave = threadIdx.x >> 6;
+    const int tx0 = blockIdx.x * 256;
+    const int x0 = tx0 + q.lane * 4;
+    const int y0 = (blockIdx.y * 4 + wave) * RY;
+    const int zb = blockIdx.z * zchunk;
+    const int ze = min(zb + zchunk, g.Dl);
+    if (y0 >= g.H) return;  // wave-uniform; there is no block-level synchronisation below
+    const bool xin = x0 < g.W;  // W % 4 == 0: a lane's four cells are all inside or all outside
+
+    // Out-of-range lanes/rows load from a safe in-range address and the value is replaced by p_air
+    // afterwards (an out-of-bounds neighbour is non-solid with pressure p_air): no divergent
+    // control flow around the loads.
+    const unsigned xs = xin ? (unsigned)x0 : 0u;
+#pragma unroll
+    for (int r = 0; r < RY; r++) {
+        q.rok[r] = xin && (y0 + r) < g.H;
+        q.boff[r] = 4u * (xs + (unsigned)g.W * (unsigned)((y0 + r) < g.H ? y0 + r : y0));
+    }
+    q.lo_ok = xin && y0 > 0;
+    q.hi_ok = xin && (y0 + RY) < g.H;
+    q.boff_lo = 4u * (xs + (unsigned)g.W * (unsigned)(y0 > 0 ? y0 - 1 : y0));
+    q.boff_hi = 4u * (xs + (unsigned)g.W * (unsigned)((y0 + RY) < g.H ? y0 + RY : y0));
+    // cells just outside this wave's x range: lane 2r = left of row r, lane 2r+1 = right of row r;
+    // lanes without an edge cell all read one wave-uniform address (a single cache-line access)
+    const int er = q.lane >> 1;
+    const int ex = (q.lane & 1) ? tx0 + 256 : tx0 - 1;
+    q.e_ok = q.lane < 2 * RY && (unsigned)ex < (unsigned)g.W && (y0 + er) < g.H;
+    q.boff_e = q.e_ok ? 4u * ((unsigned)ex + (unsigned)g.W * (unsigned)(y0 + er))
+                      : (unsigned)__builtin_amdgcn_readfirstlane((int)q.boff[0]);
+    // the z ghost plane at a domain face holds 0 (the general kernels' OOB value): p_air instead
+    q.face_lo = g.z0 == 0;
+    q.face_hi = g.z0 + g.Dl == g.Dg;
+
+    // Four register planes of Pin rotate through the roles z-1 / z / z+1 / z+2(in flight); the
+    // per-plane aux data is double-buffered.  The z loop is unrolled by 4 so the rotation is a
+    // renaming, not register moves.
+    float4 p0[RY], p1[RY], p2[RY], p3[RY];
+    CanonAux<RY> a0, a1;
+    canon_load_own<RY>(q, pin, g, zb - 1, p0);
+    canon_load_own<RY>(q, pin, g, zb, p1);
+    canon_load_own<RY>(q, pin, g, zb + 1, p2);  // zb + 1 <= Dl: at worst the upper ghost plane
+    canon_load_aux<RY>(q, mask, rhs, pin, g, zb, a0);
+    for (int lz = zb; lz < ze; lz += 4) {
+        canon_step<RY>(q, mask, rhs, pin, pout, g, lz, ze, p0, p1, p2, p3, a0, a1);
+        if (lz + 1 >= ze) break;
+        canon_step<RY>(q, mask, rhs, pin, pout, g, lz + 1, ze, p1, p2, p3, p0, a1, a0);
+        if (lz + 2 >= ze) break;
+        canon_step<RY>(q, mask, rhs, pin, pout, g, lz + 2, ze, p2, p3, p0, p1, a0, a1);
+        if (lz + 3 >= ze) break;
+        canon_step<RY>(q, mask, rhs, pin, pout, g, lz + 3, ze, p3, p0, p1, p2, a1, a0);
+    }
+}
+
 }  // namespace fluid

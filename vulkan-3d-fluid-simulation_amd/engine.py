@@ -59,7 +59,8 @@ EXPORTED_SYMBOLS = [
     "fluid_run_section", "fluid_run_section_loop", "fluid_clear_image",
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
-    "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_get_geometry", "fluid_set_option",
+    "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
+    "fluid_get_geometry", "fluid_set_option",
 ]
 
 
@@ -127,6 +128,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_section_time_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
         "fluid_reset_timing": (C.c_int, [vp]),
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
+        "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
@@ -328,6 +330,9 @@ class FluidEngine:
         return {name: self.section_time_ms(i) for i, name in enumerate(SECTION_NAMES)}
 
     # -- multi-GPU plumbing ---------------------------------------------------------------------------
+    def notify_image_written(self, image_id: int):
+        self._check(self._lib.fluid_notify_image_written(self._h, image_id))
+
     def image_plane_ptr(self, image_id: int, plane: int):
         ptr, nbytes = C.c_void_p(), C.c_uint64()
         self._check(self._lib.fluid_image_plane_ptr(self._h, image_id, plane, C.byref(ptr),

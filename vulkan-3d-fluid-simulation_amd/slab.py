@@ -121,6 +121,9 @@ class GpuSlabCompute:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    def halo_written(self, image_id: int):
+        self.engine.notify_image_written(image_id)
+
     def close(self):
         self.engine.close()
 
@@ -172,6 +175,9 @@ class HostSlabCompute:
     def sync(self):
         pass
 
+    def halo_written(self, image_id: int):
+        pass
+
     def close(self):
         pass
 
@@ -221,6 +227,8 @@ class SlabPressureSolver:
         if self.ctx.world == 1:
             return
         plan = self._plan(image_id)
+        if image_id not in (E.PRESSURES_1, E.PRESSURES_2):
+            self.compute.halo_written(image_id)  # derived data (the neighbour mask) is rebuilt
         if self.transport == "staged":
             staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
                       for snd, t, peer in plan]
