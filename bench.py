@@ -172,7 +172,7 @@ def main():
                            "parallelism": f"zslab{world}"},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "k12_zmarch (per GPU, slab)",
+                             "kernel": "k12_canon (per GPU, slab)",
                              "kernel_ms": kernel_ms},
                 "halo_exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
                 "cells_per_sec": cells * sweeps / wall,
@@ -233,7 +233,7 @@ def main():
                    "grid": [w, h, d], "jacobi_iterations": args.iters, "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k12_zmarch" if (w % 4 == 0 and w >= 64) else "k12_plain",
+                     "kernel": "k12_canon" if w % 4 == 0 else "k12_plain",
                      "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": JACOBI_BYTES_PER_CELL * cells},
         "clears_ms_per_step": clear_ms / args.steps,

@@ -358,7 +358,7 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     // solid nor water.
     const bool canon_ok = vec_ok && c->p_canon[0] && c->p_canon[1] && c->pk.t_solid != 0 &&
                           c->pk.t_water != 0;
-    if (variant == 0) variant = canon_ok ? 5 : ((vec_ok && g.W >= 64) ? 2 : 1);
+    if (variant == 0) variant = canon_ok ? 7 : ((vec_ok && g.W >= 64) ? 2 : 1);
     if (variant >= 5 && !canon_ok) variant = vec_ok ? 2 : 1;
     if (variant >= 2 && !vec_ok) variant = 1;
     if (variant == 1) {
