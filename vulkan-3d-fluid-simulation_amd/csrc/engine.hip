@@ -81,6 +81,8 @@ struct fluid_ctx {
 
     // canonical-state fast path of 12_solve_pressure (kernels_pressure.h: k12_prepare / k12_canon)
     uint64_t mask_offset = 0, rhs_offset = 0;  // internal per-cell byte mask / b_i, (Dl+2) planes
+    uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
+    BrickK bk{};
     bool mask_valid = false;   // mask matches CELL_TYPES and the cell type values
     bool rhs_valid = false;    // b_i matches DIVERGENCES and rho, dx, dt
     bool p_canon[2] = {false, false};  // every non-water cell of PRESSURES_1/2 holds p_air
@@ -204,7 +206,7 @@ ParamsK make_params_k(const fluid_params& p) {
 struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
-    uint64_t mask_offset, rhs_offset;
+    uint64_t mask_offset, rhs_offset, active_offset, active_bytes;
     uint64_t total;
 };
 
@@ -234,6 +236,10 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     off = align_up(off + plane * (uint64_t)(dl + 2), kAlign);
     L.rhs_offset = off;
     off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
+    L.active_offset = off;
+    L.active_bytes = (uint64_t)((p.fluid_size[0] + BRICK_X - 1) / BRICK_X) *
+                     ((p.fluid_size[1] + BRICK_Y - 1) / BRICK_Y) * ((dl + BRICK_Z - 1) / BRICK_Z);
+    off = align_up(off + L.active_bytes, kAlign);
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
 }
@@ -375,23 +381,25 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048) zchunk /= 2;
     const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
     if (variant >= 5) {
+        uint8_t* act = c->arena + c->active_offset;
         if (!c->mask_valid || !c->rhs_valid) {
+            if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(act, 0, c->active_bytes, c->stream));
             hipLaunchKernelGGL(k12_prepare, cell_grid(g), cell_block(), 0, c->stream, t, div,
-                               c->mask0(), c->rhs0(), g, c->pk, c->mask_valid ? 0 : 1,
+                               c->mask0(), c->rhs0(), act, c->bk, g, c->pk, c->mask_valid ? 0 : 1,
                                c->rhs_valid ? 0 : 1);
             c->mask_valid = c->rhs_valid = true;
         }
         const uint8_t* m = c->mask0();
         const float* b = c->rhs0();
         if (ry == 4)
-            hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
-                               c->pk.p_air, zchunk);
+            hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
+                               c->bk, g, c->pk.p_air, zchunk);
         else if (ry == 1)
-            hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
-                               c->pk.p_air, zchunk);
+            hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
+                               c->bk, g, c->pk.p_air, zchunk);
         else
-            hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, m, b, pin, pout, g,
-                               c->pk.p_air, zchunk);
+            hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
+                               c->bk, g, c->pk.p_air, zchunk);
     } else {
         if (ry == 4)
             hipLaunchKernelGGL(k12_zmarch<4>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
@@ -677,6 +685,11 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->particles_offset = L.particles_offset;
     c->mask_offset = L.mask_offset;
     c->rhs_offset = L.rhs_offset;
+    c->active_offset = L.active_offset;
+    c->active_bytes = L.active_bytes;
+    c->bk.nbx = (c->g.W + BRICK_X - 1) / BRICK_X;
+    c->bk.nby = (c->g.H + BRICK_Y - 1) / BRICK_Y;
+    c->bk.nbz = (c->g.Dl + BRICK_Z - 1) / BRICK_Z;
     c->arena_bytes = L.total;
 
     auto bail = [&](int code, const std::string& msg) {

@@ -248,10 +248,22 @@ k12_zmarch(const uint8_t* __restrict__ t, const float* __restrict__ div,
 //     s = b_i;  for n in +x,+y,+z,-x,-y,-z: if non-solid: s -= Pin[n], aii++;  Pout = -s/aii
 // Out-of-bounds neighbours are non-solid with pressure p_air (type 0, pressure.comp:43-47).
 
+// Activity bricks: one byte per 256 x 4 x 16 cells (x, y, z), non-zero iff the brick holds a water
+// cell.  A sweep touches nothing in a brick without water, so whole wavefronts skip such regions
+// (the reference's threads return at `if (t == cell_type_water)`, pressure.comp:69).
+constexpr int BRICK_X = 256, BRICK_Y = 4, BRICK_Z = 16;
+struct BrickK {
+    int nbx, nby, nbz;
+};
+__device__ __forceinline__ int brick_index(const BrickK& k, int bx, int by, int bz) {
+    return bx + k.nbx * (by + k.nby * bz);
+}
+
 // bit j (0..5) = neighbour j (+x,+y,+z,-x,-y,-z) is not SOLID; bit 6 = cell is WATER
 __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restrict__ div,
-                            uint8_t* __restrict__ mask, float* __restrict__ rhs, GridK g,
-                            ParamsK p, int do_mask, int do_rhs) {
+                            uint8_t* __restrict__ mask, float* __restrict__ rhs,
+                            uint8_t* __restrict__ active, BrickK bk, GridK g, ParamsK p,
+                            int do_mask, int do_rhs) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lz = blockIdx.z;
@@ -268,6 +280,8 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
         m |= ((uint32_t)t[cidx(g, x, y, lz - 1)] != p.t_solid) ? 32u : 0u;
         m |= ((uint32_t)t[id] == p.t_water) ? 64u : 0u;
         mask[id] = (uint8_t)m;
+        // same value from every writer: a benign race (the array was zeroed before this launch)
+        if (m & 64u) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
     }
 }
 
@@ -383,6 +397,8 @@ __device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t
         const float4 zm = pm[r], zp = pn[r];
         const float4 b = ac.b[r];
         const uint32_t m = ac.m[r];
+        const bool wet = (m & 0x40404040u) != 0u;  // any of the lane's four cells is water
+        if (__builtin_amdgcn_ballot_w64(wet) == 0ull) continue;  // wave-uniform: dry row segment
         float4 o;
         o.x = canon_cell(b.x, m, 0, c.y, yp.x, zp.x, left, ym.x, zm.x);
         o.y = canon_cell(b.y, m, 8, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
@@ -393,7 +409,7 @@ __device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t
         o.y = (m & 0x4000u) ? o.y : c.y;
         o.z = (m & 0x400000u) ? o.z : c.z;
         o.w = (m & 0x40000000u) ? o.w : c.w;
-        if (q.rok[r])
+        if (wet)  // rok[r] is implied: masks outside the grid are 0
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(po) + q.boff[r]) = o;
     }
 }
@@ -401,8 +417,8 @@ __device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t
 template <int RY>
 __global__ void __launch_bounds__(256)
 k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
-          const float* __restrict__ pin, float* __restrict__ pout, GridK g, float p_air,
-          int zchunk) {
+          const float* __restrict__ pin, float* __restrict__ pout,
+          const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk) {
     CanonGeom<RY> q;
     q.lane = threadIdx.x & 63;
     q.p_air = p_air;
@@ -413,6 +429,13 @@ k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const int zb = blockIdx.z * zchunk;
     const int ze = min(zb + zchunk, g.Dl);
     if (y0 >= g.H) return;  // wave-uniform; there is no block-level synchronisation below
+    {   // nothing to do if none of the bricks this wavefront covers holds water (RY divides
+        // BRICK_Y and y0 is a multiple of RY, so its rows sit in one brick row)
+        uint32_t any = 0;
+        for (int bz = zb / BRICK_Z; bz <= (ze - 1) / BRICK_Z; bz++)
+            any |= active[brick_index(bk, blockIdx.x, y0 / BRICK_Y, bz)];
+        if (any == 0) return;
+    }
     const bool xin = x0 < g.W;  // W % 4 == 0: a lane's four cells are all inside or all outside
 
     // Out-of-range lanes/rows load from a safe in-range address and the value is replaced by p_air
