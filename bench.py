@@ -44,6 +44,7 @@ def parse_args():
                     help="W [H D]; default 512^3 (BASELINE config the metric is quoted on)")
     ap.add_argument("--iters", type=int, default=200, help="Jacobi sweeps per step")
     ap.add_argument("--pressure-kernel", type=int, default=0, help="engine option (0 = auto)")
+    ap.add_argument("--no-fuse", action="store_true", help="one dispatch per sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--full-step-steps", type=int, default=3)
@@ -189,6 +190,8 @@ def main():
     eng = fluid_amd.FluidEngine(p, particle_capacity=0, pressure_iterations=args.iters,
                                 device=local_rank)
     eng.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
+    if args.no_fuse:
+        eng.set_option(E.OPT_JACOBI_FUSE, 1)
     shape = (d, h, w)
     eng.upload_image(E.CELL_TYPES, scenes.full_fluid_types(shape))
     eng.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence(shape, scenes.SEED_JACOBI + rank))

@@ -272,6 +272,20 @@ int fluid_reset_timing(fluid_ctx* ctx);
  * 0 … z_count-1 = owned planes, z_count = upper ghost plane.  Planes are contiguous in memory.    */
 int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** device_ptr,
                           uint64_t* bytes);
+/* The loop section in explicit form, for callers that must act between sweeps (halo exchange):
+ *   begin : build the solver's working buffers from PRESSURES_1 (iterate 0 -> working buffer 0)
+ *   sweep : dispatch k of the loop: working buffer k%2 -> working buffer (k+1)%2
+ *   end   : write the last two iterates into the water cells of PRESSURES_1 (even) / PRESSURES_2 (odd)
+ * begin; sweep(0..N-1); end(N) equals fluid_run_section_loop(FLUID_SEC_12_SOLVE_PRESSURE, N).  Between
+ * calls the caller exchanges the boundary planes of the buffer just written (work_plane_ptr, same
+ * plane numbering as fluid_image_plane_ptr).  Needs fluid_size.x % 4 == 0, else FLUID_ERR_UNSUPPORTED
+ * (then loop over fluid_run_pressure_dispatch and exchange the image planes instead). */
+int fluid_pressure_loop_begin(fluid_ctx* ctx);
+int fluid_pressure_loop_sweep(fluid_ctx* ctx, uint32_t k);
+int fluid_pressure_loop_end(fluid_ctx* ctx, uint32_t iterations);
+int fluid_pressure_work_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
+                                  uint64_t* bytes);
+
 /* Tell the engine that the caller wrote device memory of `image_id` through a pointer obtained
  * from fluid_image_plane_ptr (halo exchange), so data the engine derives from it is rebuilt.
  * Ghost planes of PRESSURES_1/2 must carry the neighbouring slab's cells of the same buffer. */
@@ -282,9 +296,12 @@ int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* 
 
 /* ---- engine options (performance variants of the same arithmetic; results are bit-identical) -- */
 typedef enum fluid_option {
-    FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto; 1 = one cell per thread; 2/3/4 = z-marching, 2/4/1   */
-                                   /* rows per wavefront; 5/6/7 = canonical-state fast path, 2/4/1   */
-                                   /* rows (falls back to 2 when the pressures are not canonical)    */
+    FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto.  Single dispatches: 1 = one cell per thread, 2/3/4 =  */
+                                   /* z-marching with 2/4/1 rows per wavefront.  Loop section: 1-4   */
+                                   /* = that kernel once per sweep on the images; 0/5/6/7 = working- */
+                                   /* buffer fast path with 1/2/4/1 rows per wavefront               */
+    FLUID_OPT_JACOBI_FUSE = 1,     /* loop section: 0 = two sweeps per pass over HBM (default),     */
+                                   /* 1 = one kernel launch per sweep                               */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

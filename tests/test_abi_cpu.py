@@ -70,10 +70,10 @@ def test_required_arena_bytes_is_host_arithmetic():
     p = default_params(64, 64, 64, 1000)
     n = fluid_amd.FluidEngine.required_arena_bytes(p, 1000)
     cells_with_ghosts = 64 * 64 * 66
-    # 50 B/cell of attachments + 5 B/cell of internal solver data (neighbour mask,
-    # b_i of the pressure system) + particles, each block 4-KiB aligned
-    assert n >= cells_with_ghosts * 55 + 1000 * 16
-    assert n < cells_with_ghosts * 55 + 1000 * 16 + 16 * 4096
+    # 50 B/cell of attachments + 17 B/cell of internal solver data (neighbour mask,
+    # b_i and three working buffers of the pressure loop) + particles, each block 4-KiB aligned
+    assert n >= cells_with_ghosts * 67 + 1000 * 16
+    assert n < cells_with_ghosts * 67 + 1000 * 16 + 20 * 4096
     half = fluid_amd.FluidEngine.required_arena_bytes(p, 1000, slab=(0, 32))
     assert half < n
     bad = default_params(64, 64, 64, 0)

@@ -206,16 +206,17 @@ def test_pressure_256cubed_variants_agree_and_window_matches_oracle():
     t = scenes.full_fluid_types(shape)
     div = scenes.full_fluid_divergence(shape)
     results = {}
-    for variant in (1, 2, 3, 5, 6, 7):
+    for variant in (1, 2, 3, 5, 6, 7, 0):
         with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
             eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.set_option(E.OPT_JACOBI_FUSE, 0 if variant == 0 else 1)
             eng.upload_image(E.CELL_TYPES, t)
             eng.upload_image(E.DIVERGENCES, div)
             eng.run_section("12a_clear_pressures_1")
             eng.run_section("12b_clear_pressures_2")
             eng.solve_pressure(iters)
             results[variant] = (eng.download_image(E.PRESSURES_1), eng.download_image(E.PRESSURES_2))
-    for variant in (2, 3, 5, 6, 7):
+    for variant in (2, 3, 5, 6, 7, 0):  # 0 = the default: two sweeps per pass
         assert_bit_equal(results[variant][0], results[1][0], f"P1 variant {variant} vs plain")
         assert_bit_equal(results[variant][1], results[1][1], f"P2 variant {variant} vs plain")
     z0, zc = 100, 24
@@ -332,17 +333,18 @@ def test_clear_image_arbitrary_value():
         assert_state_equal(eng, st)
 
 
-# ---- the canonical-state fast path of 12_solve_pressure (kernels_pressure.h: k12_canon) -----------------
+# ---- the loop-section fast path of 12_solve_pressure (kernels_pressure.h, kernels_pressure_fused.h) ----
 @pytest.mark.parametrize("variant", [0, 5, 6, 7])
 @pytest.mark.parametrize("size", [(24, 20, 16), (64, 64, 64), (260, 12, 9), (512, 7, 3), (256, 16, 8)])
 @pytest.mark.parametrize("iters", [1, 2, 9])
-def test_pressure_canonical_path_matches_oracle(variant, size, iters):
-    """After the two clears both pressure images are canonical (every non-water cell holds p_air)
-    and the loop runs the mask-based kernel; random types (all four kinds, no solid shell) and
-    random divergences."""
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_pressure_canonical_path_matches_oracle(variant, size, iters, fuse):
+    """The loop section on working buffers after the two clears; random types (all four kinds, no
+    solid shell) and random divergences; single-sweep and two-sweeps-per-pass schedules."""
     st = random_state(size, seed=3 * iters + variant, solid_walls=(variant % 2 == 0))
     with make_engine(st) as eng:
         eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+        eng.set_option(E.OPT_JACOBI_FUSE, fuse)
         for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
             eng.run_section(name)
             st.run_section(name)
@@ -444,3 +446,45 @@ def test_pressure_fast_path_invalidation():
         eng.solve_pressure(2)
         st.solve_pressure(2)
         check("after section 11")
+
+
+@pytest.mark.parametrize("size", [(64, 40, 24), (256, 13, 9), (512, 19, 35), (260, 6, 5), (768, 7, 6),
+                                  (1024, 5, 4), (8, 8, 8)])
+@pytest.mark.parametrize("iters", [2, 3, 4, 5, 6, 7, 8, 12])
+def test_pressure_fused_pairs_match_oracle(size, iters):
+    """Two sweeps per pass (kernels_pressure_fused.h): every pairing case of the loop schedule —
+    odd / even number of pairs, odd tail — on grids with 1, 2 and 4 x-tiles, ragged row groups and
+    z chunks, random cell types with no solid shell."""
+    st = random_state(size, seed=iters, solid_walls=False, water_fraction=0.6)
+    with make_engine(st) as eng:
+        for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
+            eng.run_section(name)
+            st.run_section(name)
+        eng.solve_pressure(iters)
+        st.solve_pressure(iters)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"],
+                           ctx=f"fused x{iters} {size}: ")
+        # a second loop on top (third buffer already canonical), then the next section of the step
+        eng.solve_pressure(iters + 1)
+        st.solve_pressure(iters + 1)
+        eng.run_section("13_fix_divergence")
+        st.run_section("13_fix_divergence")
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2", "velocities_1"],
+                           ctx=f"fused second loop {size}: ")
+
+
+def test_pressure_fused_sparse_scene_and_bricks():
+    """Mostly dry grid: the activity bricks let whole workgroups leave; results unchanged."""
+    size = (256, 40, 48)
+    st = random_state(size, seed=4, solid_walls=True)
+    st.cell_types[...] = 1  # air
+    st.cell_types[20:30, 10:22, 100:180] = CELL_WATER
+    st.cell_types[3, 3, 3] = CELL_WATER
+    st.cell_types[40:44, 30:39, 250:256] = CELL_WATER
+    with make_engine(st) as eng:
+        for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
+            eng.run_section(name)
+            st.run_section(name)
+        eng.solve_pressure(10)
+        st.solve_pressure(10)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="sparse fused: ")

@@ -81,8 +81,6 @@ def _worker(rank, world, port, size, iters, seed, out_dir):
     # case B: arbitrary uploaded pressures, odd iteration count
     comp.upload(E.PRESSURES_1, st.pressures_1[z0:z0 + n])
     comp.upload(E.PRESSURES_2, st.pressures_2[z0:z0 + n])
-    solver.exchange(E.PRESSURES_1)
-    solver.exchange(E.PRESSURES_2)
     solver.solve(iters + 1)
     b1, b2 = solver.gather_pressures()
     if rank == 0:

@@ -53,8 +53,6 @@ def _worker(rank, world, port, size, iters, seed, variant, out_dir):
     a1, a2 = solver.gather_pressures()
     comp.upload(E.PRESSURES_1, st.pressures_1[z0:z0 + n])
     comp.upload(E.PRESSURES_2, st.pressures_2[z0:z0 + n])
-    solver.exchange(E.PRESSURES_1)
-    solver.exchange(E.PRESSURES_2)
     solver.solve(iters + 1)
     b1, b2 = solver.gather_pressures()
     if rank == 0:

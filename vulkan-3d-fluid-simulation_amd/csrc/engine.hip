@@ -18,6 +18,7 @@
 #include "device_common.h"
 #include "kernels_grid.h"
 #include "kernels_pressure.h"
+#include "kernels_pressure_fused.h"
 #include "kernels_sampler.h"
 
 static_assert(sizeof(fluid_params) == FLUID_PARAMS_BYTES, "params block must be 264 bytes");
@@ -79,13 +80,17 @@ struct fluid_ctx {
     ImageDesc img[8];
     int64_t opt[FLUID_OPT_COUNT] = {0};
 
-    // canonical-state fast path of 12_solve_pressure (kernels_pressure.h: k12_prepare / k12_canon)
-    uint64_t mask_offset = 0, rhs_offset = 0;  // internal per-cell byte mask / b_i, (Dl+2) planes
+    // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
+    uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, (Dl+2) planes each
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
     BrickK bk{};
-    bool mask_valid = false;   // mask matches CELL_TYPES and the cell type values
-    bool rhs_valid = false;    // b_i matches DIVERGENCES and rho, dx, dt
-    bool p_canon[2] = {false, false};  // every non-water cell of PRESSURES_1/2 holds p_air
+    uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, (Dl+2) planes each
+    bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
+    bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
+    bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
+    bool fused_attr_set[5] = {false, false, false, false, false};
+    // explicit loop (fluid_pressure_loop_begin / _sweep / _end)
+    bool loop_open = false;
 
     bool timing = false;
     std::vector<TimerSlot> pending;
@@ -112,27 +117,22 @@ struct fluid_ctx {
     float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
     uint8_t* mask0() const { return arena + mask_offset + (uint64_t)g.plane; }
     float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + g.plane; }
+    float* work0(int i) const { return reinterpret_cast<float*>(arena + work_offset[i]) + g.plane; }
+    uint8_t* bricks() const { return arena + active_offset; }
     // bookkeeping for the fast path: call whenever an image's device contents change
     void touched(int image) {
-        switch (image) {
-            case FLUID_IMG_CELL_TYPES:
-                mask_valid = false;
-                p_canon[0] = p_canon[1] = false;
-                break;
-            case FLUID_IMG_DIVERGENCES:
-                rhs_valid = false;
-                break;
-            case FLUID_IMG_PRESSURES_1:
-                p_canon[0] = false;
-                break;
-            case FLUID_IMG_PRESSURES_2:
-                p_canon[1] = false;
-                break;
-            default:
-                break;
+        if (image == FLUID_IMG_CELL_TYPES) {
+            mask_valid = false;
+            bg_valid[0] = bg_valid[1] = bg_valid[2] = false;
+        } else if (image == FLUID_IMG_DIVERGENCES) {
+            rhs_valid = false;
         }
     }
     uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
+    void params_changed() {
+        mask_valid = rhs_valid = false;
+        bg_valid[0] = bg_valid[1] = bg_valid[2] = false;
+    }
 };
 
 #define HIP_TRY(ctx, call)                                                                    \
@@ -206,7 +206,7 @@ ParamsK make_params_k(const fluid_params& p) {
 struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
-    uint64_t mask_offset, rhs_offset, active_offset, active_bytes;
+    uint64_t mask_offset, rhs_offset, active_offset, active_bytes, work_offset[3];
     uint64_t total;
 };
 
@@ -240,6 +240,10 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     L.active_bytes = (uint64_t)((p.fluid_size[0] + BRICK_X - 1) / BRICK_X) *
                      ((p.fluid_size[1] + BRICK_Y - 1) / BRICK_Y) * ((dl + BRICK_Z - 1) / BRICK_Z);
     off = align_up(off + L.active_bytes, kAlign);
+    for (int i = 0; i < 3; i++) {
+        L.work_offset[i] = off;
+        off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
+    }
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
 }
@@ -348,7 +352,8 @@ uint32_t f32_bits(float f) {
     return u;
 }
 
-// ---- 12_solve_pressure dispatch ---------------------------------------------------------------
+// ---- 12_solve_pressure -----------------------------------------------------------------------------
+// (a) one dispatch on the images themselves, any state: k12_plain / k12_zmarch
 int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     const GridK& g = c->g;
     // pressure.comp:71-75
@@ -360,47 +365,18 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     const float* div = c->plane0<float>(FLUID_IMG_DIVERGENCES);
     int64_t variant = c->opt[FLUID_OPT_PRESSURE_KERNEL];
     const bool vec_ok = (g.W % 4 == 0);
-    // The fast path needs both buffers canonical and "type 0" (an out-of-bounds load) to be neither
-    // solid nor water.
-    const bool canon_ok = vec_ok && c->p_canon[0] && c->p_canon[1] && c->pk.t_solid != 0 &&
-                          c->pk.t_water != 0;
-    if (variant == 0) variant = canon_ok ? 7 : ((vec_ok && g.W >= 64) ? 2 : 1);
-    if (variant >= 5 && !canon_ok) variant = vec_ok ? 2 : 1;
+    if (variant == 0 || variant >= 5) variant = (vec_ok && g.W >= 64) ? 2 : 1;
     if (variant >= 2 && !vec_ok) variant = 1;
     if (variant == 1) {
         hipLaunchKernelGGL(k12_plain, cell_grid(g), cell_block(), 0, c->stream, t, div, pin, pout, g,
                            c->pk);
-        HIP_TRY(c, hipGetLastError());
-        return FLUID_OK;
-    }
-    // rows per wavefront: variants 2/5 -> 2, 3/6 -> 4, 4/7 -> 1
-    const int ry = (variant == 3 || variant == 6) ? 4 : ((variant == 4 || variant == 7) ? 1 : 2);
-    const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
-    // pick the z chunk so the launch has a few thousand workgroups (>> 256 CUs)
-    int zchunk = g.Dl;
-    while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048) zchunk /= 2;
-    const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
-    if (variant >= 5) {
-        uint8_t* act = c->arena + c->active_offset;
-        if (!c->mask_valid || !c->rhs_valid) {
-            if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(act, 0, c->active_bytes, c->stream));
-            hipLaunchKernelGGL(k12_prepare, cell_grid(g), cell_block(), 0, c->stream, t, div,
-                               c->mask0(), c->rhs0(), act, c->bk, g, c->pk, c->mask_valid ? 0 : 1,
-                               c->rhs_valid ? 0 : 1);
-            c->mask_valid = c->rhs_valid = true;
-        }
-        const uint8_t* m = c->mask0();
-        const float* b = c->rhs0();
-        if (ry == 4)
-            hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
-                               c->bk, g, c->pk.p_air, zchunk);
-        else if (ry == 1)
-            hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
-                               c->bk, g, c->pk.p_air, zchunk);
-        else
-            hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, m, b, pin, pout, act,
-                               c->bk, g, c->pk.p_air, zchunk);
     } else {
+        const int ry = variant == 3 ? 4 : (variant == 4 ? 1 : 2);
+        const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
+        int zchunk = g.Dl;  // a few thousand workgroups (>> 256 CUs)
+        while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048)
+            zchunk = (zchunk + 1) / 2;
+        const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
         if (ry == 4)
             hipLaunchKernelGGL(k12_zmarch<4>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
                                c->pk, zchunk);
@@ -413,6 +389,180 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     }
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
+}
+
+// (b) the loop section on working buffers -------------------------------------------------------------
+bool fast_loop_possible(const fluid_ctx* c) {
+    const int64_t v = c->opt[FLUID_OPT_PRESSURE_KERNEL];
+    return c->g.W % 4 == 0 && (v == 0 || v >= 5);
+}
+// what an out-of-bounds neighbour contributes: type 0 is "not solid, not water" -> p_air, unless 0
+// is the solid value (skipped -> 0) or the water value (its out-of-bounds pressure load is 0)
+float oob_value(const fluid_ctx* c) {
+    return (c->pk.t_solid == 0 || c->pk.t_water == 0) ? 0.0f : c->pk.p_air;
+}
+// cell grid over the local planes [lz0, lz0 + n)
+dim3 plane_grid(const GridK& g, int n) { return dim3((g.W + 63) / 64, (g.H + 3) / 4, n); }
+
+// mask, b_i and activity bricks, rebuilt only when CELL_TYPES / DIVERGENCES / parameters changed
+int ensure_prepared(fluid_ctx* c) {
+    if (c->mask_valid && c->rhs_valid) return FLUID_OK;
+    const GridK& g = c->g;
+    if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
+    hipLaunchKernelGGL(k12_prepare, cell_grid(g), cell_block(), 0, c->stream,
+                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                       c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(), c->bricks(),
+                       c->bk, g, c->pk, c->mask_valid ? 0 : 1, c->rhs_valid ? 0 : 1);
+    HIP_TRY(c, hipGetLastError());
+    c->mask_valid = c->rhs_valid = true;
+    return FLUID_OK;
+}
+// ghost planes that hold a neighbouring slab's cells are part of the working buffers too
+void work_plane_range(const fluid_ctx* c, int& lz0, int& n) {
+    const GridK& g = c->g;
+    const bool lo = g.z0 > 0, hi = g.z0 + g.Dl < g.Dg;
+    lz0 = lo ? -1 : 0;
+    n = g.Dl + (lo ? 1 : 0) + (hi ? 1 : 0);
+}
+int import_pressures(fluid_ctx* c, int image, int w) {
+    int lz0, n;
+    work_plane_range(c, lz0, n);
+    hipLaunchKernelGGL(k12_import, plane_grid(c->g, n), cell_block(), 0, c->stream,
+                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
+                       c->work0(w), c->g, c->pk, lz0);
+    HIP_TRY(c, hipGetLastError());
+    c->bg_valid[w] = true;
+    return FLUID_OK;
+}
+int ensure_background(fluid_ctx* c, int w) {
+    if (c->bg_valid[w]) return FLUID_OK;
+    int lz0, n;
+    work_plane_range(c, lz0, n);
+    hipLaunchKernelGGL(k12_background, plane_grid(c->g, n), cell_block(), 0, c->stream,
+                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->work0(w), c->g, c->pk, lz0);
+    HIP_TRY(c, hipGetLastError());
+    c->bg_valid[w] = true;
+    return FLUID_OK;
+}
+int export_pressures(fluid_ctx* c, int w_even, int w_odd) {
+    hipLaunchKernelGGL(k12_export, cell_grid(c->g), cell_block(), 0, c->stream,
+                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                       w_even >= 0 ? c->work0(w_even) : nullptr,
+                       w_odd >= 0 ? c->work0(w_odd) : nullptr,
+                       c->plane0<float>(FLUID_IMG_PRESSURES_1),
+                       c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+// one sweep work[src] -> work[dst] over the local planes [zlo, zhi)
+int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1) {
+    const GridK& g = c->g;
+    if (zhi < 0) zhi = g.Dl;
+    const int64_t variant = c->opt[FLUID_OPT_PRESSURE_KERNEL];
+    const int ry = variant == 6 ? 4 : (variant == 5 ? 2 : 1);  // rows per wavefront
+    const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
+    const int nz = zhi - zlo;
+    int zchunk = nz;
+    while (zchunk > 16 && (int64_t)bx * by * ((nz + zchunk - 1) / zchunk) < 2048)
+        zchunk = (zchunk + 1) / 2;
+    const dim3 grid(bx, by, (nz + zchunk - 1) / zchunk);
+    const float* pin = c->work0(src);
+    float* pout = c->work0(dst);
+    const float oob = oob_value(c);
+    if (ry == 4)
+        hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
+                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
+    else if (ry == 2)
+        hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
+                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
+    else
+        hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
+                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+// two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
+// j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
+template <int NT>
+int launch_fused_nt(fluid_ctx* c, int src, int dst, int mid) {
+    const GridK& g = c->g;
+    const size_t lds = fused_lds_bytes(NT);
+    if (!c->fused_attr_set[NT]) {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->fused_attr_set[NT] = true;
+    }
+    constexpr int TY = FUSED_WAVES / NT - 2;
+    const int by = (g.H + TY - 1) / TY;
+    int zchunk = g.Dl;
+    while (zchunk > 32 && (int64_t)by * ((g.Dl + zchunk - 1) / zchunk) < 1024)
+        zchunk = (zchunk + 1) / 2;
+    const dim3 grid(1, by, (g.Dl + zchunk - 1) / zchunk);
+    hipLaunchKernelGGL(k12_canon2<NT>, grid, dim3(FUSED_THREADS), lds, c->stream, c->mask0(),
+                       c->rhs0(), c->work0(src), c->work0(dst), mid >= 0 ? c->work0(mid) : nullptr,
+                       c->bricks(), c->bk, g, oob_value(c), zchunk);
+    HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
+    const int nt = (c->g.W + 255) / 256;
+    switch (nt) {
+        case 1: return launch_fused_nt<1>(c, src, dst, mid);
+        case 2: return launch_fused_nt<2>(c, src, dst, mid);
+        case 3:
+        case 4: return launch_fused_nt<4>(c, src, dst, mid);
+        default: return c->fail(FLUID_ERR_UNSUPPORTED, "fused sweeps need W <= 1024");
+    }
+}
+
+// FlowLoopPushConstantSection on working buffers: import PRESSURES_1, N sweeps, export the last
+// two iterates.  Iterate k lives in a working buffer; dispatch k of the reference maps iterate k
+// (read from PRESSURES_1 if k is even, else PRESSURES_2) to iterate k+1 in the other image.
+int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
+    if (iterations == 0) return FLUID_OK;
+    int rc = ensure_prepared(c);
+    if (rc) return rc;
+    rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);  // iterate 0 -> work[0]
+    if (rc) return rc;
+    const bool fuse = !c->is_slab && c->g.W <= 1024 && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
+    int cur = 0;          // buffer of the newest iterate
+    int prev = -1;        // buffer of the iterate before it (valid when >= 0)
+    uint32_t k = 0;       // index of the newest iterate
+    auto other = [](int a, int b) {  // a working buffer that is neither a nor b
+        for (int i = 0; i < 3; i++)
+            if (i != a && i != b) return i;
+        return -1;
+    };
+    if (fuse) {
+        // Two sweeps per pass over HBM; only the last pair of an even-length loop also writes the
+        // odd iterate N-1 (which 13_fix_divergence will read from PRESSURES_2).
+        const uint32_t pairs = iterations / 2;
+        for (uint32_t p = 0; p < pairs && rc == FLUID_OK; p++) {
+            const bool need_mid = (p + 1 == pairs) && (iterations % 2u == 0u);
+            const int dst = other(cur, cur);
+            const int mid = need_mid ? other(cur, dst) : -1;
+            rc = ensure_background(c, dst);
+            if (rc == FLUID_OK && mid >= 0) rc = ensure_background(c, mid);
+            if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid);
+            prev = mid;
+            cur = dst;
+            k += 2;
+        }
+    }
+    while (k < iterations && rc == FLUID_OK) {  // single sweeps: the whole loop, or an odd tail
+        const int dst = other(cur, prev >= 0 ? prev : cur);
+        rc = ensure_background(c, dst);
+        if (rc == FLUID_OK) rc = launch_work_sweep(c, cur, dst);
+        prev = cur;
+        cur = dst;
+        k++;
+    }
+    if (rc) return rc;
+    // iterate N and N-1: the even one belongs in PRESSURES_1, the odd one in PRESSURES_2
+    const bool n_even = (iterations % 2u) == 0u;
+    return export_pressures(c, n_even ? cur : prev, n_even ? prev : cur);
 }
 
 int slab_unsupported(fluid_ctx* c, const char* what) {
@@ -496,11 +646,9 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case FLUID_SEC_12A_CLEAR_PRESSURES_1:
             c->pressure_dispatch_index = 0;
-            c->p_canon[0] = true;  // every cell holds p_air
             return fill_image(c, FLUID_IMG_PRESSURES_1, f32_bits(pk.p_air));
         case FLUID_SEC_12B_CLEAR_PRESSURES_2:
             c->pressure_dispatch_index = 0;
-            c->p_canon[1] = true;
             return fill_image(c, FLUID_IMG_PRESSURES_2, f32_bits(pk.p_air));
         case FLUID_SEC_12_SOLVE_PRESSURE: {
             const uint32_t even = (c->pressure_dispatch_index % 2u) == 0u ? 1u : 0u;
@@ -687,6 +835,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->rhs_offset = L.rhs_offset;
     c->active_offset = L.active_offset;
     c->active_bytes = L.active_bytes;
+    for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
     c->bk.nbx = (c->g.W + BRICK_X - 1) / BRICK_X;
     c->bk.nby = (c->g.H + BRICK_Y - 1) / BRICK_Y;
     c->bk.nbz = (c->g.Dl + BRICK_Z - 1) / BRICK_Z;
@@ -815,8 +964,7 @@ int fluid_set_params(fluid_ctx* c, const void* blob) {
             return c->fail(FLUID_ERR_SIZE_MISMATCH, "fluid_size cannot change on a live context");
     c->params = p;
     c->pk = make_params_k(p);
-    c->mask_valid = c->rhs_valid = false;  // cell type values, rho, dx, dt, p_air may have changed
-    c->p_canon[0] = c->p_canon[1] = false;
+    c->params_changed();  // cell type values, rho, dx, dt, p_air may have changed
     return FLUID_OK;
 }
 
@@ -894,10 +1042,8 @@ int fluid_clear_image(fluid_ctx* c, int image_id, const uint32_t value_bits[4]) 
     if (!value_bits) return c->fail(FLUID_ERR_INVALID_ARG, "null clear value");
     HIP_TRY(c, hipSetDevice(c->device));
     c->touched(image_id);
-    if (image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2) {
+    if (image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2)
         c->pressure_dispatch_index = 0;
-        c->p_canon[image_id - FLUID_IMG_PRESSURES_1] = value_bits[0] == f32_bits(c->pk.p_air);
-    }
     return fill_image4(c, image_id, value_bits);
 }
 
@@ -912,6 +1058,57 @@ int fluid_run_pressure_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {
     return rc ? rc : rc2;
 }
 
+// ---- the loop section in explicit form (multi-GPU: the caller exchanges halos between sweeps) ----
+int fluid_pressure_loop_begin(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!fast_loop_possible(c))
+        return c->fail(FLUID_ERR_UNSUPPORTED,
+                       "the working-buffer loop needs fluid_size.x %% 4 == 0 (and pressure kernel "
+                       "option 0 or >= 5); use fluid_run_pressure_dispatch per sweep instead");
+    int rc = ensure_prepared(c);
+    if (rc == FLUID_OK) rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);
+    if (rc == FLUID_OK) rc = ensure_background(c, 1);
+    c->loop_open = rc == FLUID_OK;
+    return rc;
+}
+
+int fluid_pressure_loop_sweep(fluid_ctx* c, uint32_t k) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    SectionTimer tm{c};
+    int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
+    if (rc) return rc;
+    rc = launch_work_sweep(c, (int)(k & 1u), (int)((k + 1u) & 1u));
+    int rc2 = tm.end();
+    return rc ? rc : rc2;
+}
+
+int fluid_pressure_loop_end(fluid_ctx* c, uint32_t iterations) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->loop_open = false;
+    c->pressure_dispatch_index = iterations;
+    if (iterations == 0) return FLUID_OK;
+    // iterate k lives in work[k % 2]: the even iterate goes to PRESSURES_1, the odd to PRESSURES_2
+    return export_pressures(c, 0, 1);
+}
+
+int fluid_pressure_work_plane_ptr(fluid_ctx* c, int which, int32_t plane, void** device_ptr,
+                                  uint64_t* bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (which < 0 || which > 1) return c->fail(FLUID_ERR_INVALID_ARG, "working buffer %d", which);
+    if (plane < -1 || plane > c->g.Dl)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [-1, %d]", plane, c->g.Dl);
+    const uint64_t pb = (uint64_t)c->g.plane * 4;
+    *device_ptr = c->arena + c->work_offset[which] + (uint64_t)(plane + 1) * pb;
+    *bytes = pb;
+    return FLUID_OK;
+}
+
 int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (section_id != FLUID_SEC_12_SOLVE_PRESSURE)
@@ -923,8 +1120,12 @@ int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
     SectionTimer tm{c};
     int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
     if (rc) return rc;
-    for (uint32_t k = 0; k < iterations && rc == FLUID_OK; k++)
-        rc = launch_pressure(c, (k % 2u) == 0u ? 1u : 0u);
+    if (fast_loop_possible(c)) {
+        rc = run_fast_loop(c, iterations);
+    } else {
+        for (uint32_t k = 0; k < iterations && rc == FLUID_OK; k++)
+            rc = launch_pressure(c, (k % 2u) == 0u ? 1u : 0u);
+    }
     c->pressure_dispatch_index = iterations;
     int rc2 = tm.end();
     if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && iterations > 1)
@@ -1022,10 +1223,7 @@ int fluid_notify_image_written(fluid_ctx* c, int image_id) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
-    // Halo planes of the pressures arrive from the neighbouring slab in the neighbour's (canonical
-    // or not) state, which is this slab's state too: only derived data is invalidated.
-    if (image_id == FLUID_IMG_CELL_TYPES) c->mask_valid = false;
-    if (image_id == FLUID_IMG_DIVERGENCES) c->rhs_valid = false;
+    c->touched(image_id);  // derived data (neighbour mask, b_i, working-buffer constants) is rebuilt
     return FLUID_OK;
 }
 

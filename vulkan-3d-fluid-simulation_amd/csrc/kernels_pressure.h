@@ -232,21 +232,25 @@ k12_zmarch(const uint8_t* __restrict__ t, const float* __restrict__ div,
 
 
 // ---------------------------------------------------------------------------------------------
-// The canonical-state fast path.
+// The loop-section fast path: sweeps on internal working buffers.
 //
-// Observation (pressure.comp:41-50,69): a sweep never writes a non-water cell, and for a non-solid
-// non-water neighbour it subtracts p_air instead of reading Pin.  After the clears of
-// fluid_flow_sections.h:298-299 every non-water cell of PRESSURES_1/2 HOLDS p_air and keeps it for
-// the whole loop ("canonical" buffers; the engine tracks this, see engine.hip).  Then
-//     (t == water ? Pin[n] : p_air)  ==  Pin[n]        for every non-solid neighbour n,
-// so a sweep needs, per cell, only: is the cell water, which of its 6 neighbours are non-solid
-// (7 bits), Pin, and the sweep-invariant b_i = ((div*rho)*dx)/dt.  k12_prepare packs the 7 bits
-// into one byte per cell and evaluates b_i once per loop; k12_canon then moves exactly the
-// algorithmic 13 B/cell (mask 1 + b 4 + Pin 4 + Pout 4) with no type-neighbourhood traffic, and
-// stores Pin's own value for non-water cells (== what Pout already holds), which keeps every store
-// a full 16-byte vector.  Arithmetic per water cell is the shader's, in the shader's order:
-//     s = b_i;  for n in +x,+y,+z,-x,-y,-z: if non-solid: s -= Pin[n], aii++;  Pout = -s/aii
-// Out-of-bounds neighbours are non-solid with pressure p_air (type 0, pressure.comp:43-47).
+// pressure.comp:41-50,69: a sweep never writes a non-water cell; a SOLID neighbour contributes
+// nothing; a non-solid non-water neighbour contributes p_air instead of its stored pressure.  So a
+// whole loop can run on working copies of the pressure in which every cell holds exactly what it
+// contributes as a neighbour:
+//     water cell: its current iterate      solid cell: +0.0f      any other cell: p_air
+// (k12_import builds such a copy from PRESSURES_1; s - 0.0f == s bit for bit, so subtracting a solid
+// neighbour's 0 is the shader's "skip").  A sweep then needs per cell only the byte
+// {is water, number of non-solid neighbours}, the working pressure and the sweep-invariant
+// b_i = ((div*rho)*dx)/dt, all of it streamed once: mask 1 + b 4 + Pin 4 + Pout 4 = the algorithmic
+// 13 B/cell, no type-neighbourhood traffic, no data-dependent branches, every store a full 16-byte
+// vector (non-water cells re-store their own constant).  Per water cell, in the shader's order:
+//     s = b_i;  s -= W[+x]; s -= W[+y]; s -= W[+z]; s -= W[-x]; s -= W[-y]; s -= W[-z];
+//     Wout = -s / aii
+// Out-of-bounds neighbours contribute `p_oob` (type 0: p_air unless 0 is the solid or the water type
+// value, in which case the shader's out-of-bounds arithmetic yields 0).  k12_export writes the last
+// two iterates back into the water cells of PRESSURES_1 / PRESSURES_2; non-water cells of the images
+// are never touched, exactly as in the reference.  Valid for any image contents and parameters.
 
 // Activity bricks: one byte per 256 x 4 x 16 cells (x, y, z), non-zero iff the brick holds a water
 // cell.  A sweep touches nothing in a brick without water, so whole wavefronts skip such regions
@@ -285,6 +289,46 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
     }
 }
 
+// Working-buffer value of a cell that is not water (what it contributes as a neighbour).
+__device__ __forceinline__ float background_value(uint32_t type, const ParamsK& p) {
+    return type == p.t_solid ? 0.0f : p.p_air;
+}
+
+// PRESSURES_1 -> working buffer (all planes incl. ghosts that hold neighbour slabs' cells)
+__global__ void k12_import(const uint8_t* __restrict__ t, const float* __restrict__ pimg,
+                           float* __restrict__ work, GridK g, ParamsK p, int lz0) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = lz0 + (int)blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    const uint32_t ty = t[id];
+    work[id] = ty == p.t_water ? pimg[id] : background_value(ty, p);
+}
+// constant part of a working buffer: non-water cells (water cells are written by the sweeps)
+__global__ void k12_background(const uint8_t* __restrict__ t, float* __restrict__ work, GridK g,
+                               ParamsK p, int lz0) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = lz0 + (int)blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    work[id] = background_value(t[id], p);
+}
+// working buffers -> water cells of PRESSURES_1 (even iterate) and PRESSURES_2 (odd iterate)
+__global__ void k12_export(const uint8_t* __restrict__ t, const float* __restrict__ w_even,
+                           const float* __restrict__ w_odd, float* __restrict__ p1,
+                           float* __restrict__ p2, GridK g, ParamsK p) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    if ((uint32_t)t[id] != p.t_water) return;  // pressure.comp:69
+    if (w_even) p1[id] = w_even[id];
+    if (w_odd) p2[id] = w_odd[id];
+}
+
 // lane i <- lane i-1 / lane i+1 across the whole wavefront (DPP wave_shr:1 / wave_shl:1);
 // lanes 0 / 63 receive `edge`.
 __device__ __forceinline__ float from_lane_below(float v, float edge, int lane) {
@@ -296,24 +340,19 @@ __device__ __forceinline__ float from_lane_above(float v, float edge, int lane) 
     return lane == 63 ? edge : __int_as_float(r);
 }
 
-// one water cell; m6 = its mask byte; q* = Pin of the six neighbours
+// one water cell: b = b_i, bits [sh, sh+6) of m = its non-solid-neighbour flags, q* = working
+// pressures of the six neighbours (solid ones hold +0.0f)
 __device__ __forceinline__ float canon_cell(float b, uint32_t m, int sh, float qxp, float qyp,
                                             float qzp, float qxm, float qym, float qzm) {
-    // (bit ? q : +0.0f): s - 0.0f == s bit for bit, so the conditional subtraction of the shader
-    // becomes an AND with a sign-extended bit
-    auto pick = [&](float q, int j) -> float {
-        const int ext = __builtin_amdgcn_sbfe(m, sh + j, 1);  // 0 or -1
-        return __int_as_float(__float_as_int(q) & ext);
-    };
     float s = b;
-    s = s - pick(qxp, 0);
-    s = s - pick(qyp, 1);
-    s = s - pick(qzp, 2);
-    s = s - pick(qxm, 3);
-    s = s - pick(qym, 4);
-    s = s - pick(qzm, 5);
+    s = s - qxp;  // pressure.comp:56-61 order: +x, +y, +z, -x, -y, -z
+    s = s - qyp;
+    s = s - qzp;
+    s = s - qxm;
+    s = s - qym;
+    s = s - qzm;
     const float aii = (float)__builtin_popcount((m >> sh) & 63u);
-    return -s / aii;
+    return -s / aii;  // :62
 }
 
 template <int RY>
@@ -331,7 +370,7 @@ struct CanonGeom {
     unsigned boff_lo, boff_hi, boff_e;
     bool rok[RY], lo_ok, hi_ok, e_ok, face_lo, face_hi;
     int lane;
-    float p_air;
+    float p_air;  // value of an out-of-bounds neighbour (p_oob)
 };
 
 __device__ __forceinline__ float4 ld_f4(const float* base, unsigned byte_off) {
@@ -404,7 +443,7 @@ __device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t
         o.y = canon_cell(b.y, m, 8, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
         o.z = canon_cell(b.z, m, 16, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
         o.w = canon_cell(b.w, m, 24, right, yp.w, zp.w, c.z, ym.w, zm.w);
-        // non-water cells keep their value: Pout already equals Pin there (both canonical)
+        // non-water cells re-store their own constant (the output buffer holds the same one)
         o.x = (m & 0x40u) ? o.x : c.x;
         o.y = (m & 0x4000u) ? o.y : c.y;
         o.z = (m & 0x400000u) ? o.z : c.z;
@@ -418,7 +457,8 @@ template <int RY>
 __global__ void __launch_bounds__(256)
 k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
           const float* __restrict__ pin, float* __restrict__ pout,
-          const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk) {
+          const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk,
+          int zlo, int zhi) {
     CanonGeom<RY> q;
     q.lane = threadIdx.x & 63;
     q.p_air = p_air;
@@ -426,8 +466,8 @@ k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const int tx0 = blockIdx.x * 256;
     const int x0 = tx0 + q.lane * 4;
     const int y0 = (blockIdx.y * 4 + wave) * RY;
-    const int zb = blockIdx.z * zchunk;
-    const int ze = min(zb + zchunk, g.Dl);
+    const int zb = zlo + blockIdx.z * zchunk;  // this launch sweeps the local planes [zlo, zhi)
+    const int ze = min(zb + zchunk, zhi);
     if (y0 >= g.H) return;  // wave-uniform; there is no block-level synchronisation below
     {   // nothing to do if none of the bricks this wavefront covers holds water (RY divides
         // BRICK_Y and y0 is a multiple of RY, so its rows sit in one brick row)
@@ -439,8 +479,8 @@ k12_canon(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const bool xin = x0 < g.W;  // W % 4 == 0: a lane's four cells are all inside or all outside
 
     // Out-of-range lanes/rows load from a safe in-range address and the value is replaced by p_air
-    // afterwards (an out-of-bounds neighbour is non-solid with pressure p_air): no divergent
-    // control flow around the loads.
+    // afterwards (what an out-of-bounds neighbour contributes): no divergent control flow around the
+    // loads.
     const unsigned xs = xin ? (unsigned)x0 : 0u;
 #pragma unroll
     for (int r = 0; r < RY; r++) {

@@ -46,6 +46,7 @@ SECTION_COUNT = len(SECTION_NAMES)
 
 DIFFUSE_REFERENCE_EXACT, DIFFUSE_INTENDED = 0, 1
 OPT_PRESSURE_KERNEL = 0
+OPT_JACOBI_FUSE = 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
     0, -1, -2, -3, -4, -5, -6)
@@ -60,6 +61,8 @@ EXPORTED_SYMBOLS = [
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
+    "fluid_pressure_loop_begin", "fluid_pressure_loop_sweep", "fluid_pressure_loop_end",
+    "fluid_pressure_work_plane_ptr",
     "fluid_get_geometry", "fluid_set_option",
 ]
 
@@ -129,6 +132,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_reset_timing": (C.c_int, [vp]),
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
+        "fluid_pressure_loop_begin": (C.c_int, [vp]),
+        "fluid_pressure_loop_sweep": (C.c_int, [vp, u32]),
+        "fluid_pressure_loop_end": (C.c_int, [vp, u32]),
+        "fluid_pressure_work_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
+                                                    C.POINTER(u64)]),
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
@@ -330,6 +338,21 @@ class FluidEngine:
         return {name: self.section_time_ms(i) for i, name in enumerate(SECTION_NAMES)}
 
     # -- multi-GPU plumbing ---------------------------------------------------------------------------
+    def pressure_loop_begin(self):
+        self._check(self._lib.fluid_pressure_loop_begin(self._h))
+
+    def pressure_loop_sweep(self, k: int):
+        self._check(self._lib.fluid_pressure_loop_sweep(self._h, k))
+
+    def pressure_loop_end(self, iterations: int):
+        self._check(self._lib.fluid_pressure_loop_end(self._h, iterations))
+
+    def pressure_work_plane_ptr(self, which: int, plane: int):
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.fluid_pressure_work_plane_ptr(self._h, which, plane, C.byref(ptr),
+                                                            C.byref(nbytes)))
+        return int(ptr.value), int(nbytes.value)
+
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))
 

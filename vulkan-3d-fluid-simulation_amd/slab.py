@@ -97,6 +97,8 @@ class GpuSlabCompute:
             arena=base + self._pad, arena_bytes=nbytes)
         self.engine.set_option(E.OPT_PRESSURE_KERNEL, pressure_kernel)
         self._base = base
+        # working-buffer loop (fluid_pressure_loop_*) when the engine offers it for this grid
+        self.fast = params.size[0] % 4 == 0 and pressure_kernel in (0, 5, 6, 7)
 
     def plane(self, image_id: int, local_z: int):
         ptr, nbytes = self.engine.image_plane_ptr(image_id, local_z)
@@ -104,6 +106,18 @@ class GpuSlabCompute:
         view = self.arena[off:off + nbytes]
         dtype, _ = E.IMAGE_DTYPES[image_id]
         return view.view(self.torch.float32) if dtype == np.float32 else view
+
+    def _view(self, ptr: int, nbytes: int, as_float: bool):
+        off = ptr - self._base
+        view = self.arena[off:off + nbytes]
+        return view.view(self.torch.float32) if as_float else view
+
+    def work_plane(self, which: int, local_z: int):
+        """Plane of the buffer that holds the iterates of parity `which` during a loop: the
+        engine's working buffer (fast path) or the pressure image itself."""
+        if self.fast:
+            return self._view(*self.engine.pressure_work_plane_ptr(which, local_z), True)
+        return self.plane(E.PRESSURES_1 if which == 0 else E.PRESSURES_2, local_z)
 
     def upload(self, image_id: int, array: np.ndarray):
         self.engine.upload_image(image_id, array)
@@ -115,8 +129,20 @@ class GpuSlabCompute:
         self.engine.run_section("12a_clear_pressures_1")
         self.engine.run_section("12b_clear_pressures_2")
 
-    def dispatch(self, is_even_iteration: int):
-        self.engine.run_pressure_dispatch(is_even_iteration)
+    # the loop section in explicit form (include/fluid_engine.h: fluid_pressure_loop_*)
+    def loop_begin(self):
+        if self.fast:
+            self.engine.pressure_loop_begin()
+
+    def loop_sweep(self, k: int):
+        if self.fast:
+            self.engine.pressure_loop_sweep(k)
+        else:
+            self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
+
+    def loop_end(self, iterations: int):
+        if self.fast:
+            self.engine.pressure_loop_end(iterations)
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -157,11 +183,21 @@ class HostSlabCompute:
     def download(self, image_id: int) -> np.ndarray:
         return self.arr[image_id][1:-1].numpy().copy()
 
+    def work_plane(self, which: int, local_z: int):
+        return self.plane(E.PRESSURES_1 if which == 0 else E.PRESSURES_2, local_z)
+
     def clear_pressures(self):
         self.arr[E.PRESSURES_1][1:-1] = float(self.params.pressure_air)
         self.arr[E.PRESSURES_2][1:-1] = float(self.params.pressure_air)
 
-    def dispatch(self, is_even_iteration: int):
+    def loop_begin(self):
+        pass
+
+    def loop_end(self, iterations: int):
+        pass
+
+    def loop_sweep(self, k: int):
+        is_even_iteration = 1 if k % 2 == 0 else 0
         src = E.PRESSURES_1 if is_even_iteration == 1 else E.PRESSURES_2
         dst = E.PRESSURES_2 if is_even_iteration == 1 else E.PRESSURES_1
         out = self.arr[dst].numpy()
@@ -219,16 +255,24 @@ class SlabPressureSolver:
         return self
 
     # -- halo exchange ---------------------------------------------------------------------------------
-    def exchange(self, image_id: int):
+    def _run_plan(self, key, make_plane):
         """Send the first/last owned plane to the lower/upper neighbour, receive their last/first
-        owned plane into the ghost planes.  Grouped point-to-point, both directions at once."""
+        owned plane into the ghost planes.  Grouped point-to-point, both directions at once.  The
+        tensor views and P2POps are built once per buffer and reused (the planes never move)."""
         import torch.distributed as dist
 
         if self.ctx.world == 1:
             return
-        plan = self._plan(image_id)
-        if image_id not in (E.PRESSURES_1, E.PRESSURES_2):
-            self.compute.halo_written(image_id)  # derived data (the neighbour mask) is rebuilt
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = []  # (is_send, plane tensor, peer)
+            if self.lo is not None:
+                plan.append((True, make_plane(0), self.lo))
+                plan.append((False, make_plane(-1), self.lo))
+            if self.hi is not None:
+                plan.append((True, make_plane(self.z_count - 1), self.hi))
+                plan.append((False, make_plane(self.z_count), self.hi))
+            self._plans[key] = plan
         if self.transport == "staged":
             staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
                       for snd, t, peer in plan]
@@ -240,45 +284,39 @@ class SlabPressureSolver:
                 if not snd:
                     t.copy_(h)
             return
-        ops = self._ops.get(image_id)
+        ops = self._ops.get(key)
         if ops is None:
             ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer) for snd, t, peer in plan]
-            self._ops[image_id] = ops
+            self._ops[key] = ops
         for work in dist.batch_isend_irecv(ops):
             work.wait()
 
-    def _plan(self, image_id: int):
-        """(is_send, plane tensor, peer) for this image — tensor views are built once and reused
-        (the planes never move)."""
-        plan = self._plans.get(image_id)
-        if plan is None:
-            c = self.compute
-            plan = []
-            if self.lo is not None:
-                plan.append((True, c.plane(image_id, 0), self.lo))
-                plan.append((False, c.plane(image_id, -1), self.lo))
-            if self.hi is not None:
-                plan.append((True, c.plane(image_id, self.z_count - 1), self.hi))
-                plan.append((False, c.plane(image_id, self.z_count), self.hi))
-            self._plans[image_id] = plan
-        return plan
+    def exchange(self, image_id: int):
+        """Halo exchange of an image (cell types at set-up)."""
+        self._run_plan(("img", image_id), lambda z: self.compute.plane(image_id, z))
+        self.compute.halo_written(image_id)  # derived data (the neighbour mask) is rebuilt
+
+    def exchange_work(self, which: int):
+        """Halo exchange of the buffer holding the iterates of parity `which`."""
+        self._run_plan(("work", which), lambda z: self.compute.work_plane(which, z))
 
     # -- the loop section ---------------------------------------------------------------------------------
     def clear_pressures(self):
         self.compute.clear_pressures()
-        # ghost planes between slabs must read p_air as well: take them from the neighbours
-        self.exchange(E.PRESSURES_1)
-        self.exchange(E.PRESSURES_2)
 
     def solve(self, iterations: Optional[int] = None):
-        """FlowLoopPushConstantSection semantics: dispatch k reads PRESSURES_1 and
-        writes PRESSURES_2 iff k is even; after every dispatch the written buffer's halo planes are
-        exchanged so the next dispatch sees the neighbours' new values."""
+        """FlowLoopPushConstantSection semantics: dispatch k maps iterate k (parity
+        k%2; PRESSURES_1 holds the even ones) to iterate k+1.  After every dispatch the boundary
+        planes of the buffer just written are exchanged so the next dispatch sees the neighbours'
+        new values."""
         n = self.iterations if iterations is None else iterations
+        c = self.compute
+        c.loop_begin()
+        self.exchange_work(0)           # iterate 0
         for k in range(n):
-            even = 1 if k % 2 == 0 else 0
-            self.compute.dispatch(even)
-            self.exchange(E.PRESSURES_2 if even else E.PRESSURES_1)
+            c.loop_sweep(k)
+            self.exchange_work((k + 1) % 2)
+        c.loop_end(n)
 
     def step(self):
         self.clear_pressures()
