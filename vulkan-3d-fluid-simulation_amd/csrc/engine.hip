@@ -17,8 +17,7 @@
 #include "../../include/fluid_engine.h"
 #include "device_common.h"
 #include "kernels_grid.h"
-#include "kernels_pressure.h"
-#include "kernels_pressure_fused.h"
+#include "pressure_api.h"
 #include "kernels_sampler.h"
 
 static_assert(sizeof(fluid_params) == FLUID_PARAMS_BYTES, "params block must be 264 bytes");
@@ -83,12 +82,10 @@ struct fluid_ctx {
     // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, (Dl+2) planes each
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
-    BrickK bk{};
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, (Dl+2) planes each
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
     bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
     bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
-    bool fused_attr_set[5] = {false, false, false, false, false};
     // explicit loop (fluid_pressure_loop_begin / _sweep / _end)
     bool loop_open = false;
 
@@ -237,8 +234,11 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     L.rhs_offset = off;
     off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
     L.active_offset = off;
-    L.active_bytes = (uint64_t)((p.fluid_size[0] + BRICK_X - 1) / BRICK_X) *
-                     ((p.fluid_size[1] + BRICK_Y - 1) / BRICK_Y) * ((dl + BRICK_Z - 1) / BRICK_Z);
+    {
+        int nbx, nby, nbz;
+        k12_brick_dims((int)p.fluid_size[0], (int)p.fluid_size[1], (int)dl, nbx, nby, nbz);
+        L.active_bytes = (uint64_t)nbx * nby * nbz;
+    }
     off = align_up(off + L.active_bytes, kAlign);
     for (int i = 0; i < 3; i++) {
         L.work_offset[i] = off;
@@ -367,26 +367,11 @@ int launch_pressure(fluid_ctx* c, uint32_t is_even_iteration) {
     const bool vec_ok = (g.W % 4 == 0);
     if (variant == 0 || variant >= 5) variant = (vec_ok && g.W >= 64) ? 2 : 1;
     if (variant >= 2 && !vec_ok) variant = 1;
-    if (variant == 1) {
-        hipLaunchKernelGGL(k12_plain, cell_grid(g), cell_block(), 0, c->stream, t, div, pin, pout, g,
-                           c->pk);
-    } else {
-        const int ry = variant == 3 ? 4 : (variant == 4 ? 1 : 2);
-        const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
-        int zchunk = g.Dl;  // a few thousand workgroups (>> 256 CUs)
-        while (zchunk > 16 && (int64_t)bx * by * ((g.Dl + zchunk - 1) / zchunk) < 2048)
-            zchunk = (zchunk + 1) / 2;
-        const dim3 grid(bx, by, (g.Dl + zchunk - 1) / zchunk);
-        if (ry == 4)
-            hipLaunchKernelGGL(k12_zmarch<4>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
-                               c->pk, zchunk);
-        else if (ry == 1)
-            hipLaunchKernelGGL(k12_zmarch<1>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
-                               c->pk, zchunk);
-        else
-            hipLaunchKernelGGL(k12_zmarch<2>, grid, dim3(256), 0, c->stream, t, div, pin, pout, g,
-                               c->pk, zchunk);
-    }
+    if (variant == 1)
+        k12_launch_plain(c->stream, t, div, pin, pout, g, c->pk);
+    else
+        k12_launch_zmarch(c->stream, variant == 3 ? 4 : (variant == 4 ? 1 : 2), t, div, pin, pout, g,
+                          c->pk);
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -401,18 +386,14 @@ bool fast_loop_possible(const fluid_ctx* c) {
 float oob_value(const fluid_ctx* c) {
     return (c->pk.t_solid == 0 || c->pk.t_water == 0) ? 0.0f : c->pk.p_air;
 }
-// cell grid over the local planes [lz0, lz0 + n)
-dim3 plane_grid(const GridK& g, int n) { return dim3((g.W + 63) / 64, (g.H + 3) / 4, n); }
-
 // mask, b_i and activity bricks, rebuilt only when CELL_TYPES / DIVERGENCES / parameters changed
 int ensure_prepared(fluid_ctx* c) {
     if (c->mask_valid && c->rhs_valid) return FLUID_OK;
     const GridK& g = c->g;
     if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
-    hipLaunchKernelGGL(k12_prepare, cell_grid(g), cell_block(), 0, c->stream,
-                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
-                       c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(), c->bricks(),
-                       c->bk, g, c->pk, c->mask_valid ? 0 : 1, c->rhs_valid ? 0 : 1);
+    k12_launch_prepare(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                       c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(), c->bricks(), g,
+                       c->pk, !c->mask_valid, !c->rhs_valid);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = c->rhs_valid = true;
     return FLUID_OK;
@@ -427,9 +408,8 @@ void work_plane_range(const fluid_ctx* c, int& lz0, int& n) {
 int import_pressures(fluid_ctx* c, int image, int w) {
     int lz0, n;
     work_plane_range(c, lz0, n);
-    hipLaunchKernelGGL(k12_import, plane_grid(c->g, n), cell_block(), 0, c->stream,
-                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
-                       c->work0(w), c->g, c->pk, lz0);
+    k12_launch_import(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
+                      c->work0(w), c->g, c->pk, lz0, n);
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[w] = true;
     return FLUID_OK;
@@ -438,83 +418,40 @@ int ensure_background(fluid_ctx* c, int w) {
     if (c->bg_valid[w]) return FLUID_OK;
     int lz0, n;
     work_plane_range(c, lz0, n);
-    hipLaunchKernelGGL(k12_background, plane_grid(c->g, n), cell_block(), 0, c->stream,
-                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->work0(w), c->g, c->pk, lz0);
+    k12_launch_background(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->work0(w), c->g,
+                          c->pk, lz0, n);
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[w] = true;
     return FLUID_OK;
 }
 int export_pressures(fluid_ctx* c, int w_even, int w_odd) {
-    hipLaunchKernelGGL(k12_export, cell_grid(c->g), cell_block(), 0, c->stream,
-                       c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
-                       w_even >= 0 ? c->work0(w_even) : nullptr,
-                       w_odd >= 0 ? c->work0(w_odd) : nullptr,
-                       c->plane0<float>(FLUID_IMG_PRESSURES_1),
-                       c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
+    k12_launch_export(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                      w_even >= 0 ? c->work0(w_even) : nullptr,
+                      w_odd >= 0 ? c->work0(w_odd) : nullptr, c->plane0<float>(FLUID_IMG_PRESSURES_1),
+                      c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
 
 // one sweep work[src] -> work[dst] over the local planes [zlo, zhi)
 int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1) {
-    const GridK& g = c->g;
-    if (zhi < 0) zhi = g.Dl;
+    if (zhi < 0) zhi = c->g.Dl;
     const int64_t variant = c->opt[FLUID_OPT_PRESSURE_KERNEL];
     const int ry = variant == 6 ? 4 : (variant == 5 ? 2 : 1);  // rows per wavefront
-    const int bx = (g.W + 255) / 256, by = (g.H + 4 * ry - 1) / (4 * ry);
-    const int nz = zhi - zlo;
-    int zchunk = nz;
-    while (zchunk > 16 && (int64_t)bx * by * ((nz + zchunk - 1) / zchunk) < 2048)
-        zchunk = (zchunk + 1) / 2;
-    const dim3 grid(bx, by, (nz + zchunk - 1) / zchunk);
-    const float* pin = c->work0(src);
-    float* pout = c->work0(dst);
-    const float oob = oob_value(c);
-    if (ry == 4)
-        hipLaunchKernelGGL(k12_canon<4>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
-                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
-    else if (ry == 2)
-        hipLaunchKernelGGL(k12_canon<2>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
-                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
-    else
-        hipLaunchKernelGGL(k12_canon<1>, grid, dim3(256), 0, c->stream, c->mask0(), c->rhs0(), pin,
-                           pout, c->bricks(), c->bk, g, oob, zchunk, zlo, zhi);
+    k12_launch_canon(c->stream, ry, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst), c->bricks(),
+                     c->g, oob_value(c), zlo, zhi);
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
 
 // two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
 // j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
-template <int NT>
-int launch_fused_nt(fluid_ctx* c, int src, int dst, int mid) {
-    const GridK& g = c->g;
-    const size_t lds = fused_lds_bytes(NT);
-    if (!c->fused_attr_set[NT]) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->fused_attr_set[NT] = true;
-    }
-    constexpr int TY = FUSED_WAVES / NT - 2;
-    const int by = (g.H + TY - 1) / TY;
-    int zchunk = g.Dl;
-    while (zchunk > 32 && (int64_t)by * ((g.Dl + zchunk - 1) / zchunk) < 1024)
-        zchunk = (zchunk + 1) / 2;
-    const dim3 grid(1, by, (g.Dl + zchunk - 1) / zchunk);
-    hipLaunchKernelGGL(k12_canon2<NT>, grid, dim3(FUSED_THREADS), lds, c->stream, c->mask0(),
-                       c->rhs0(), c->work0(src), c->work0(dst), mid >= 0 ? c->work0(mid) : nullptr,
-                       c->bricks(), c->bk, g, oob_value(c), zchunk);
+int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
+    HIP_TRY(c, k12_launch_canon2(c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
+                                 mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
+                                 oob_value(c)));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
-}
-int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
-    const int nt = (c->g.W + 255) / 256;
-    switch (nt) {
-        case 1: return launch_fused_nt<1>(c, src, dst, mid);
-        case 2: return launch_fused_nt<2>(c, src, dst, mid);
-        case 3:
-        case 4: return launch_fused_nt<4>(c, src, dst, mid);
-        default: return c->fail(FLUID_ERR_UNSUPPORTED, "fused sweeps need W <= 1024");
-    }
 }
 
 // FlowLoopPushConstantSection on working buffers: import PRESSURES_1, N sweeps, export the last
@@ -526,7 +463,7 @@ int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
     if (rc) return rc;
     rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);  // iterate 0 -> work[0]
     if (rc) return rc;
-    const bool fuse = !c->is_slab && c->g.W <= 1024 && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
+    const bool fuse = k12_canon2_supports(c->g) && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
     int cur = 0;          // buffer of the newest iterate
     int prev = -1;        // buffer of the iterate before it (valid when >= 0)
     uint32_t k = 0;       // index of the newest iterate
@@ -836,9 +773,6 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->active_offset = L.active_offset;
     c->active_bytes = L.active_bytes;
     for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
-    c->bk.nbx = (c->g.W + BRICK_X - 1) / BRICK_X;
-    c->bk.nby = (c->g.H + BRICK_Y - 1) / BRICK_Y;
-    c->bk.nbz = (c->g.Dl + BRICK_Z - 1) / BRICK_Z;
     c->arena_bytes = L.total;
 
     auto bail = [&](int code, const std::string& msg) {

@@ -15,7 +15,7 @@
 //               plus one halo row above and below.
 #pragma once
 
-#include "device_common.h"
+#include "pressure_common.h"
 
 namespace fluid {
 
@@ -252,17 +252,6 @@ k12_zmarch(const uint8_t* __restrict__ t, const float* __restrict__ div,
 // two iterates back into the water cells of PRESSURES_1 / PRESSURES_2; non-water cells of the images
 // are never touched, exactly as in the reference.  Valid for any image contents and parameters.
 
-// Activity bricks: one byte per 256 x 4 x 16 cells (x, y, z), non-zero iff the brick holds a water
-// cell.  A sweep touches nothing in a brick without water, so whole wavefronts skip such regions
-// (the reference's threads return at `if (t == cell_type_water)`, pressure.comp:69).
-constexpr int BRICK_X = 256, BRICK_Y = 4, BRICK_Z = 16;
-struct BrickK {
-    int nbx, nby, nbz;
-};
-__device__ __forceinline__ int brick_index(const BrickK& k, int bx, int by, int bz) {
-    return bx + k.nbx * (by + k.nby * bz);
-}
-
 // bit j (0..5) = neighbour j (+x,+y,+z,-x,-y,-z) is not SOLID; bit 6 = cell is WATER
 __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restrict__ div,
                             uint8_t* __restrict__ mask, float* __restrict__ rhs,
@@ -287,11 +276,6 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
         // same value from every writer: a benign race (the array was zeroed before this launch)
         if (m & 64u) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
     }
-}
-
-// Working-buffer value of a cell that is not water (what it contributes as a neighbour).
-__device__ __forceinline__ float background_value(uint32_t type, const ParamsK& p) {
-    return type == p.t_solid ? 0.0f : p.p_air;
 }
 
 // PRESSURES_1 -> working buffer (all planes incl. ghosts that hold neighbour slabs' cells)
@@ -329,32 +313,6 @@ __global__ void k12_export(const uint8_t* __restrict__ t, const float* __restric
     if (w_odd) p2[id] = w_odd[id];
 }
 
-// lane i <- lane i-1 / lane i+1 across the whole wavefront (DPP wave_shr:1 / wave_shl:1);
-// lanes 0 / 63 receive `edge`.
-__device__ __forceinline__ float from_lane_below(float v, float edge, int lane) {
-    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false);
-    return lane == 0 ? edge : __int_as_float(r);
-}
-__device__ __forceinline__ float from_lane_above(float v, float edge, int lane) {
-    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false);
-    return lane == 63 ? edge : __int_as_float(r);
-}
-
-// one water cell: b = b_i, bits [sh, sh+6) of m = its non-solid-neighbour flags, q* = working
-// pressures of the six neighbours (solid ones hold +0.0f)
-__device__ __forceinline__ float canon_cell(float b, uint32_t m, int sh, float qxp, float qyp,
-                                            float qzp, float qxm, float qym, float qzm) {
-    float s = b;
-    s = s - qxp;  // pressure.comp:56-61 order: +x, +y, +z, -x, -y, -z
-    s = s - qyp;
-    s = s - qzp;
-    s = s - qxm;
-    s = s - qym;
-    s = s - qzm;
-    const float aii = (float)__builtin_popcount((m >> sh) & 63u);
-    return -s / aii;  // :62
-}
-
 template <int RY>
 struct CanonAux {       // per-plane data that is only needed for the plane being computed
     float4 b[RY];       // b_i of the wave's own rows
@@ -373,9 +331,6 @@ struct CanonGeom {
     float p_air;  // value of an out-of-bounds neighbour (p_oob)
 };
 
-__device__ __forceinline__ float4 ld_f4(const float* base, unsigned byte_off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
 
 template <int RY>
 __device__ __forceinline__ void canon_load_own(const CanonGeom<RY>& q, const float* pin,

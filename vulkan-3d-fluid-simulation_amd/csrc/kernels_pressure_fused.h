@@ -24,9 +24,26 @@
 // and rows outside the grid are the constant p_oob for both iterates.
 #pragma once
 
-#include "kernels_pressure.h"
+#include "pressure_common.h"
 
 namespace fluid {
+
+#define FLUID_LDS __attribute__((address_space(3)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_ld4(const FLUID_LDS float* p) {
+    const f32x4 v = *(const FLUID_LDS f32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_st4(FLUID_LDS float* p, float4 v) {
+    const f32x4 r = {v.x, v.y, v.z, v.w};
+    *(FLUID_LDS f32x4*)p = r;
+}
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* base, unsigned byte_off) {
+    return *reinterpret_cast<const uint32_t*>(base + byte_off);
+}
+__device__ __forceinline__ void st_f4(float* base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 
 constexpr int FUSED_WAVES = 16;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
@@ -47,9 +64,10 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     constexpr int TY = R - 2;             // output rows per workgroup
     constexpr int RW = NT * 256 + 2 * FUSED_PAD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef FLUID_LDS float lds_f;
     // lds layout: [buf][array J=0 / S=1][row][RW]
-    auto row_ptr = [&](int buf, int arr, int row) -> float* {
-        return lds + ((size_t)((buf * 2 + arr) * R + row)) * RW + FUSED_PAD;
+    auto row_ptr = [&](int buf, int arr, int row) -> lds_f* {
+        return (lds_f*)lds + ((buf * 2 + arr) * R + row) * RW + FUSED_PAD;
     };
 
     const int lane = threadIdx.x & 63;
@@ -84,55 +102,51 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const unsigned boff_h =
         4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)yh < (unsigned)g.H) ? yh : 0));
 
+    // Loads are unconditional, from a valid address (plane pointer redirected to plane 0 when the
+    // plane lies outside the grid), and the value is fixed up afterwards, late: a branch or a select
+    // directly on a load makes hipcc wait for it (vmcnt(0)) on the spot, which would expose the HBM
+    // latency in every step.
     auto plane_ok = [&](int lz) { return lz >= 0 && lz < g.Dl; };  // whole-grid context
-    auto load_j = [&](int lz, unsigned off, bool ok) -> float4 {
-        if (!plane_ok(lz)) return pa4;  // wave-uniform
-        const float4 v = ld_f4(pin + (int64_t)lz * g.plane, off);
-        return ok ? v : pa4;
-    };
-    auto load_b = [&](int lz) -> float4 {
-        if (!plane_ok(lz)) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return ld_f4(rhs + (int64_t)lz * g.plane, boff);
-    };
-    auto load_m = [&](int lz) -> uint32_t {
-        if (!plane_ok(lz)) return 0u;
-        const uint32_t m =
-            *reinterpret_cast<const uint32_t*>(mask + (int64_t)lz * g.plane + (boff >> 2));
-        return row_in ? m : 0u;
-    };
+    auto fix_j = [&](float4 v, bool ok, int lz) { return (ok && plane_ok(lz)) ? v : pa4; };
+    const uint32_t lane_mask = row_in ? 0xFFFFFFFFu : 0u;  // masks outside the grid read as 0
+    auto fix_m = [&](uint32_t m, int lz) { return plane_ok(lz) ? (m & lane_mask) : 0u; };
 
     // pad cells of every LDS row: x = -1 and x = NT*256 read as p_air (outside the grid)
     for (int i = threadIdx.x; i < 2 * 2 * R * 2 * FUSED_PAD; i += FUSED_THREADS) {
         const int side = i % (2 * FUSED_PAD), row = i / (2 * FUSED_PAD);
-        float* base = lds + (size_t)row * RW;
+        lds_f* base = (lds_f*)lds + row * RW;
         base[side < FUSED_PAD ? side : RW - 2 * FUSED_PAD + side] = p_air;
     }
 
     // registers: iterate j at planes zc-1, zc, zc+1 (+ zc+2 in flight); iterate j+1 at zc-2, zc-1
     int zc = zb - 1;  // plane of iterate j+1 computed in the coming step
-    float4 jm = load_j(zc - 1, boff, row_in), jc = load_j(zc, boff, row_in),
-           jn = load_j(zc + 1, boff, row_in), jnn;
-    float4 hc = load_j(zc, boff_h, halo_in), hn;   // halo waves: outer y-neighbour row, plane zc
+    auto pl = [&](const float* base, int lz) {  // wave-uniform plane pointer, always inside the image
+        return base + (int64_t)(plane_ok(lz) ? lz : 0) * g.plane;
+    };
+    float4 jm = fix_j(ld_f4(pl(pin, zc - 1), boff), row_in, zc - 1);
+    float4 jc = fix_j(ld_f4(pl(pin, zc), boff), row_in, zc);
+    float4 jn = fix_j(ld_f4(pl(pin, zc + 1), boff), row_in, zc + 1), jnn;
+    float4 hc = fix_j(ld_f4(pl(pin, zc), boff_h), halo_in, zc), hn;  // halo waves: outer y row
     float4 s_mm = pa4, s_m = pa4, s_c;
-    float4 b_c = load_b(zc), b_m = make_float4(0.f, 0.f, 0.f, 0.f), b_n;
-    uint32_t m_c = load_m(zc), m_m = 0u, m_n;
+    float4 b_c = ld_f4(pl(rhs, zc), boff), b_m = make_float4(0.f, 0.f, 0.f, 0.f), b_n;
+    uint32_t m_c = fix_m(ld_u32(mask + (pl(rhs, zc) - rhs), boff >> 2), zc), m_m = 0u, m_n;
     // the address of the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4
     const int xe = lane == 0 ? x0 - 1 : x0 + 4;
 
     const int steps = ze - zb + 2;
     for (int k = 0; k < steps; k++, zc++) {
         const int buf = k & 1;
-        // ---- loads the next step needs
-        jnn = load_j(zc + 2, boff, row_in);
-        hn = load_j(zc + 1, boff_h, halo_in);
-        b_n = load_b(zc + 1);
-        m_n = load_m(zc + 1);
+        // ---- loads the next step needs (raw; fixed up at the rotation below)
+        jnn = ld_f4(pl(pin, zc + 2), boff);
+        hn = ld_f4(pl(pin, zc + 1), boff_h);
+        b_n = ld_f4(pl(rhs, zc + 1), boff);
+        m_n = ld_u32(mask + (pl(rhs, zc + 1) - rhs), boff >> 2);
 
         // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
-        float* jrow = row_ptr(buf, 0, rr);
-        float* srow = row_ptr(buf, 1, rr);
-        *reinterpret_cast<float4*>(jrow + x0) = jc;
-        *reinterpret_cast<float4*>(srow + x0) = s_m;
+        lds_f* jrow = row_ptr(buf, 0, rr);
+        lds_f* srow = row_ptr(buf, 1, rr);
+        lds_st4(jrow + x0, jc);
+        lds_st4(srow + x0, s_m);
         __syncthreads();
 
         // ---- stage 1: iterate j+1 at plane zc for this row
@@ -140,10 +154,8 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
             const bool wet = (m_c & 0x40404040u) != 0u;
             s_c = jc;  // non-water (and out-of-grid) cells keep p_air
             if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
-                const float4 ym = halo_lo ? hc : *reinterpret_cast<const float4*>(
-                                                     row_ptr(buf, 0, halo_lo ? rr : rr - 1) + x0);
-                const float4 yp = halo_hi ? hc : *reinterpret_cast<const float4*>(
-                                                     row_ptr(buf, 0, halo_hi ? rr : rr + 1) + x0);
+                const float4 ym = halo_lo ? hc : lds_ld4(row_ptr(buf, 0, halo_lo ? rr : rr - 1) + x0);
+                const float4 yp = halo_hi ? hc : lds_ld4(row_ptr(buf, 0, halo_hi ? rr : rr + 1) + x0);
                 const float e = jrow[xe];
                 const float left = from_lane_below(jc.w, e, lane);
                 const float right = from_lane_above(jc.x, e, lane);
@@ -164,8 +176,8 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         if (zo >= zb && zo < ze && rr >= 1 && rr <= R - 2) {  // wave-uniform
             const bool wet = is_out_row && (m_m & 0x40404040u) != 0u;
             if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
-                const float4 ym = *reinterpret_cast<const float4*>(row_ptr(buf, 1, rr - 1) + x0);
-                const float4 yp = *reinterpret_cast<const float4*>(row_ptr(buf, 1, rr + 1) + x0);
+                const float4 ym = lds_ld4(row_ptr(buf, 1, rr - 1) + x0);
+                const float4 yp = lds_ld4(row_ptr(buf, 1, rr + 1) + x0);
                 const float e = srow[xe];
                 const float left = from_lane_below(s_m.w, e, lane);
                 const float right = from_lane_above(s_m.x, e, lane);
@@ -179,26 +191,24 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
                 o.z = (m_m & 0x400000u) ? o.z : s_m.z;
                 o.w = (m_m & 0x40000000u) ? o.w : s_m.w;
                 if (wet) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(pout + (int64_t)zo * g.plane) +
-                                               boff) = o;
+                    st_f4(pout + (int64_t)zo * g.plane, boff, o);
                     if (pmid)  // the odd iterate, kept only by the last pair of a loop
-                        *reinterpret_cast<float4*>(
-                            reinterpret_cast<char*>(pmid + (int64_t)zo * g.plane) + boff) = s_m;
+                        st_f4(pmid + (int64_t)zo * g.plane, boff, s_m);
                 }
             }
         }
 
-        // ---- rotate
+        // ---- rotate (and fix up what was loaded for the next step)
         jm = jc;
         jc = jn;
-        jn = jnn;
-        hc = hn;
+        jn = fix_j(jnn, row_in, zc + 2);
+        hc = fix_j(hn, halo_in, zc + 1);
         s_mm = s_m;
         s_m = s_c;
         b_m = b_c;
         b_c = b_n;
         m_m = m_c;
-        m_c = m_n;
+        m_c = fix_m(m_n, zc + 1);
     }
 }
 

@@ -1,0 +1,42 @@
+// pressure_api.h — host-callable launchers of the 12_solve_pressure kernels.  The kernels live in two
+// translation units of their own (pressure_sweep.hip, pressure_fused.hip; see pressure_common.h for
+// why); engine.hip only sees these declarations.  Every launcher enqueues on `s` and returns.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+
+namespace fluid {
+
+struct BrickK;  // pressure_common.h
+
+// activity-brick geometry for a grid (host arithmetic)
+void k12_brick_dims(int W, int H, int Dl, int& nbx, int& nby, int& nbz);
+
+// single dispatch on the images (any state)
+void k12_launch_plain(hipStream_t s, const uint8_t* t, const float* div, const float* pin,
+                      float* pout, const GridK& g, const ParamsK& p);
+void k12_launch_zmarch(hipStream_t s, int rows_per_wave, const uint8_t* t, const float* div,
+                       const float* pin, float* pout, const GridK& g, const ParamsK& p);
+
+// loop section on working buffers
+void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask, float* rhs,
+                        uint8_t* bricks, const GridK& g, const ParamsK& p, bool do_mask, bool do_rhs);
+void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
+                       const GridK& g, const ParamsK& p, int lz0, int nplanes);
+void k12_launch_background(hipStream_t s, const uint8_t* t, float* work, const GridK& g,
+                           const ParamsK& p, int lz0, int nplanes);
+void k12_launch_export(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
+                       float* p1, float* p2, const GridK& g, const ParamsK& p);
+void k12_launch_canon(hipStream_t s, int rows_per_wave, const uint8_t* mask, const float* rhs,
+                      const float* pin, float* pout, const uint8_t* bricks, const GridK& g,
+                      float p_oob, int zlo, int zhi);
+// two sweeps per pass; returns a hipError_t from the one-time LDS attribute call (hipSuccess else)
+hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
+                             float p_oob);
+bool k12_canon2_supports(const GridK& g);
+
+}  // namespace fluid

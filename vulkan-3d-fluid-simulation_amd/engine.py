@@ -160,8 +160,8 @@ class FluidEngine:
     def __init__(self, params: FluidParams, particle_capacity: int = 0,
                  pressure_iterations: int = 200, device: int = -1,
                  slab: Optional[tuple] = None, stream: int = 0, arena: int = 0,
-                 arena_bytes: int = 0):
-        self._lib = load_library()
+                 arena_bytes: int = 0, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
         self._h = C.c_void_p()
         self._blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
         info = CreateInfo()
