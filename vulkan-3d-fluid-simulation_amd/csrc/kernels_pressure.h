@@ -252,7 +252,7 @@ k12_zmarch(const uint8_t* __restrict__ t, const float* __restrict__ div,
 // two iterates back into the water cells of PRESSURES_1 / PRESSURES_2; non-water cells of the images
 // are never touched, exactly as in the reference.  Valid for any image contents and parameters.
 
-// bit j (0..5) = neighbour j (+x,+y,+z,-x,-y,-z) is not SOLID; bit 6 = cell is WATER
+// mask byte: number of non-SOLID neighbours if the cell is WATER, MASK_DRY otherwise
 __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restrict__ div,
                             uint8_t* __restrict__ mask, float* __restrict__ rhs,
                             uint8_t* __restrict__ active, BrickK bk, GridK g, ParamsK p,
@@ -265,16 +265,16 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
     if (do_rhs) rhs[id] = ((div[id] * p.rho) * p.dx) / p.dt;  // pressure.comp:54
     if (do_mask) {
         uint32_t m = 0;
-        m |= (type_at(t, g, x + 1, y, lz) != p.t_solid) ? 1u : 0u;
-        m |= (type_at(t, g, x, y + 1, lz) != p.t_solid) ? 2u : 0u;
-        m |= ((uint32_t)t[cidx(g, x, y, lz + 1)] != p.t_solid) ? 4u : 0u;
-        m |= (type_at(t, g, x - 1, y, lz) != p.t_solid) ? 8u : 0u;
-        m |= (type_at(t, g, x, y - 1, lz) != p.t_solid) ? 16u : 0u;
-        m |= ((uint32_t)t[cidx(g, x, y, lz - 1)] != p.t_solid) ? 32u : 0u;
-        m |= ((uint32_t)t[id] == p.t_water) ? 64u : 0u;
-        mask[id] = (uint8_t)m;
+        m += (type_at(t, g, x + 1, y, lz) != p.t_solid) ? 1u : 0u;
+        m += (type_at(t, g, x, y + 1, lz) != p.t_solid) ? 1u : 0u;
+        m += ((uint32_t)t[cidx(g, x, y, lz + 1)] != p.t_solid) ? 1u : 0u;
+        m += (type_at(t, g, x - 1, y, lz) != p.t_solid) ? 1u : 0u;
+        m += (type_at(t, g, x, y - 1, lz) != p.t_solid) ? 1u : 0u;
+        m += ((uint32_t)t[cidx(g, x, y, lz - 1)] != p.t_solid) ? 1u : 0u;
+        const bool water = (uint32_t)t[id] == p.t_water;
+        mask[id] = (uint8_t)(water ? m : MASK_DRY);
         // same value from every writer: a benign race (the array was zeroed before this launch)
-        if (m & 64u) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
+        if (water) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
     }
 }
 
@@ -357,7 +357,7 @@ __device__ __forceinline__ void canon_load_aux(const CanonGeom<RY>& q, const uin
     for (int r = 0; r < RY; r++) {
         a.b[r] = ld_f4(rr, q.boff[r]);
         const uint32_t m = *reinterpret_cast<const uint32_t*>(mm + (q.boff[r] >> 2));
-        a.m[r] = q.rok[r] ? m : 0u;  // outside the grid: not water, nothing computed or stored
+        a.m[r] = q.rok[r] ? m : MASK_DRY4;  // outside the grid: not water, nothing computed or stored
     }
     const float4 lo = ld_f4(pp, q.boff_lo), hi = ld_f4(pp, q.boff_hi);
     a.hl = q.lo_ok ? lo : pa4;
@@ -391,18 +391,18 @@ __device__ __forceinline__ void canon_step(const CanonGeom<RY>& q, const uint8_t
         const float4 zm = pm[r], zp = pn[r];
         const float4 b = ac.b[r];
         const uint32_t m = ac.m[r];
-        const bool wet = (m & 0x40404040u) != 0u;  // any of the lane's four cells is water
+        const bool wet = mask_any_water(m);  // any of the lane's four cells is water
         if (__builtin_amdgcn_ballot_w64(wet) == 0ull) continue;  // wave-uniform: dry row segment
         float4 o;
         o.x = canon_cell(b.x, m, 0, c.y, yp.x, zp.x, left, ym.x, zm.x);
-        o.y = canon_cell(b.y, m, 8, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
-        o.z = canon_cell(b.z, m, 16, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
-        o.w = canon_cell(b.w, m, 24, right, yp.w, zp.w, c.z, ym.w, zm.w);
+        o.y = canon_cell(b.y, m, 1, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
+        o.z = canon_cell(b.z, m, 2, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
+        o.w = canon_cell(b.w, m, 3, right, yp.w, zp.w, c.z, ym.w, zm.w);
         // non-water cells re-store their own constant (the output buffer holds the same one)
-        o.x = (m & 0x40u) ? o.x : c.x;
-        o.y = (m & 0x4000u) ? o.y : c.y;
-        o.z = (m & 0x400000u) ? o.z : c.z;
-        o.w = (m & 0x40000000u) ? o.w : c.w;
+        o.x = mask_is_water(m, 0) ? o.x : c.x;
+        o.y = mask_is_water(m, 1) ? o.y : c.y;
+        o.z = mask_is_water(m, 2) ? o.z : c.z;
+        o.w = mask_is_water(m, 3) ? o.w : c.w;
         if (wet)  // rok[r] is implied: masks outside the grid are 0
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(po) + q.boff[r]) = o;
     }

@@ -55,6 +55,140 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
     return (size_t)2 /*buffers*/ * 2 /*J,S*/ * r * fused_row_floats(nt) * sizeof(float);
 }
 
+// Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
+// 4, so ring indices are compile-time constants and the rotation costs no register moves):
+//   j[4]  iterate j   : slots (i, i+1, i+2) = planes zc-1, zc, zc+1; slot i+3 receives plane zc+2
+//   s[4]  iterate j+1 : slots (i, i+1) = planes zc-2, zc-1; slot i+2 receives plane zc
+//   b[4], m[4]        : slots (i+1, i+2) = planes zc-1 (stage 2), zc (stage 1); slot i+3 receives zc+1
+//   h[2]  halo row    : slot i&1 = plane zc; the other receives plane zc+1   (halo wavefronts only)
+struct FusedState {
+    float4 j[4], s[4], b[4], h[2];
+    uint32_t m[4];
+};
+
+template <int NT>
+struct FusedCtx {
+    static constexpr int R = FUSED_WAVES / NT;
+    static constexpr int RW = NT * 256 + 2 * FUSED_PAD;
+    const uint8_t* mask;
+    const float* rhs;
+    const float* pin;
+    float* pout;
+    float* pmid;
+    FLUID_LDS float* lds;
+    int64_t plane;
+    int Dl, zb, ze;
+    int lane, rr, x0, xe;
+    unsigned boff, boff_h;
+    float p_oob;
+    bool row_in, halo_in, halo_lo, halo_hi, is_out_row;
+    bool wave_clean;     // every lane of this wavefront lies inside the grid (wave-uniform)
+    uint32_t lane_mask;  // ~0 for lanes inside the grid
+
+    __device__ __forceinline__ FLUID_LDS float* row_ptr(int buf, int arr, int row) const {
+        return lds + ((buf * 2 + arr) * R + row) * RW + FUSED_PAD;
+    }
+    __device__ __forceinline__ bool plane_ok(int lz) const { return lz >= 0 && lz < Dl; }
+    // element offset of plane lz, redirected to plane 0 when lz is outside the grid: loads are always
+    // issued, from a valid address, and the value is replaced later (fix_*).  A branch or a select
+    // directly on a load makes hipcc wait for it (vmcnt(0)) on the spot.
+    __device__ __forceinline__ int64_t plane_off(int lz) const {
+        return plane_ok(lz) ? (int64_t)lz * plane : (int64_t)0;
+    }
+    __device__ __forceinline__ float4 fix_j(float4 v, bool ok, int lz) const {
+        if (wave_clean && plane_ok(lz)) return v;  // wave-uniform: the common case costs nothing
+        const float4 pa4 = make_float4(p_oob, p_oob, p_oob, p_oob);
+        return (ok && plane_ok(lz)) ? v : pa4;
+    }
+    __device__ __forceinline__ uint32_t fix_m(uint32_t m, int lz) const {
+        if (wave_clean && plane_ok(lz)) return m;
+        return plane_ok(lz) ? ((m & lane_mask) | (MASK_DRY4 & ~lane_mask)) : MASK_DRY4;
+    }
+};
+
+// One plane step: I = ring phase (k mod 4), zc = plane of iterate j+1 formed in this step.
+template <int NT, int I>
+__device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st, int zc) {
+    constexpr int R = FusedCtx<NT>::R;
+    constexpr int buf = I & 1;
+    float4& jm = st.j[I & 3];
+    float4& jc = st.j[(I + 1) & 3];
+    float4& jn = st.j[(I + 2) & 3];   // raw from the previous step's load until fixed up below
+    float4& s_mm = st.s[I & 3];
+    float4& s_m = st.s[(I + 1) & 3];
+    float4& s_c = st.s[(I + 2) & 3];
+    const float4 b_m = st.b[(I + 1) & 3], b_c = st.b[(I + 2) & 3];
+    const uint32_t m_m = st.m[(I + 1) & 3];
+
+    // ---- loads the next step needs (raw; fixed up at the end of this step)
+    const int64_t o1 = c.plane_off(zc + 1), o2 = c.plane_off(zc + 2);
+    st.j[(I + 3) & 3] = ld_f4(c.pin + o2, c.boff);
+    st.h[(I + 1) & 1] = ld_f4(c.pin + o1, c.boff_h);
+    st.b[(I + 3) & 3] = ld_f4(c.rhs + o1, c.boff);
+    st.m[(I + 3) & 3] = ld_u32(c.mask + o1, c.boff >> 2);
+
+    // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
+    FLUID_LDS float* jrow = c.row_ptr(buf, 0, c.rr);
+    FLUID_LDS float* srow = c.row_ptr(buf, 1, c.rr);
+    lds_st4(jrow + c.x0, jc);
+    lds_st4(srow + c.x0, s_m);
+    __syncthreads();
+
+    // ---- fix up what the previous step loaded (only wavefronts / planes on the grid boundary do
+    // anything here; by now those loads have had a whole step to land)
+    jn = c.fix_j(jn, c.row_in, zc + 1);
+    const float4 hc = c.fix_j(st.h[I & 1], c.halo_in, zc);
+    const uint32_t m_c = c.fix_m(st.m[(I + 2) & 3], zc);
+    st.m[(I + 2) & 3] = m_c;
+
+    // ---- stage 1: iterate j+1 at plane zc for this row
+    s_c = jc;  // non-water (and out-of-grid) cells keep their constant
+    if (__builtin_amdgcn_ballot_w64(mask_any_water(m_c)) != 0ull) {
+        const float4 ym = c.halo_lo ? hc : lds_ld4(c.row_ptr(buf, 0, c.halo_lo ? c.rr : c.rr - 1) + c.x0);
+        const float4 yp = c.halo_hi ? hc : lds_ld4(c.row_ptr(buf, 0, c.halo_hi ? c.rr : c.rr + 1) + c.x0);
+        const float e = jrow[c.xe];
+        const float left = from_lane_below(jc.w, e, c.lane);
+        const float right = from_lane_above(jc.x, e, c.lane);
+        float4 o;
+        o.x = canon_cell(b_c.x, m_c, 0, jc.y, yp.x, jn.x, left, ym.x, jm.x);
+        o.y = canon_cell(b_c.y, m_c, 1, jc.z, yp.y, jn.y, jc.x, ym.y, jm.y);
+        o.z = canon_cell(b_c.z, m_c, 2, jc.w, yp.z, jn.z, jc.y, ym.z, jm.z);
+        o.w = canon_cell(b_c.w, m_c, 3, right, yp.w, jn.w, jc.z, ym.w, jm.w);
+        s_c.x = mask_is_water(m_c, 0) ? o.x : jc.x;
+        s_c.y = mask_is_water(m_c, 1) ? o.y : jc.y;
+        s_c.z = mask_is_water(m_c, 2) ? o.z : jc.z;
+        s_c.w = mask_is_water(m_c, 3) ? o.w : jc.w;
+    }
+
+    // ---- stage 2: iterate j+2 at plane zc-1 from iterate j+1 at planes zc-2, zc-1, zc
+    const int zo = zc - 1;
+    if (zo >= c.zb && zo < c.ze && c.rr >= 1 && c.rr <= R - 2) {  // wave-uniform
+        const bool wet = c.is_out_row && mask_any_water(m_m);
+        if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
+            const float4 ym = lds_ld4(c.row_ptr(buf, 1, c.rr - 1) + c.x0);
+            const float4 yp = lds_ld4(c.row_ptr(buf, 1, c.rr + 1) + c.x0);
+            const float e = srow[c.xe];
+            const float left = from_lane_below(s_m.w, e, c.lane);
+            const float right = from_lane_above(s_m.x, e, c.lane);
+            float4 o;
+            o.x = canon_cell(b_m.x, m_m, 0, s_m.y, yp.x, s_c.x, left, ym.x, s_mm.x);
+            o.y = canon_cell(b_m.y, m_m, 1, s_m.z, yp.y, s_c.y, s_m.x, ym.y, s_mm.y);
+            o.z = canon_cell(b_m.z, m_m, 2, s_m.w, yp.z, s_c.z, s_m.y, ym.z, s_mm.z);
+            o.w = canon_cell(b_m.w, m_m, 3, right, yp.w, s_c.w, s_m.z, ym.w, s_mm.w);
+            o.x = mask_is_water(m_m, 0) ? o.x : s_m.x;
+            o.y = mask_is_water(m_m, 1) ? o.y : s_m.y;
+            o.z = mask_is_water(m_m, 2) ? o.z : s_m.z;
+            o.w = mask_is_water(m_m, 3) ? o.w : s_m.w;
+            if (wet) {
+                const int64_t oo = (int64_t)zo * c.plane;
+                st_f4(c.pout + oo, c.boff, o);
+                if (c.pmid)  // the odd iterate, kept only by the last pair of a loop
+                    st_f4(c.pmid + oo, c.boff, s_m);
+            }
+        }
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(FUSED_THREADS)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
@@ -64,151 +198,87 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     constexpr int TY = R - 2;             // output rows per workgroup
     constexpr int RW = NT * 256 + 2 * FUSED_PAD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    typedef FLUID_LDS float lds_f;
-    // lds layout: [buf][array J=0 / S=1][row][RW]
-    auto row_ptr = [&](int buf, int arr, int row) -> lds_f* {
-        return (lds_f*)lds + ((buf * 2 + arr) * R + row) * RW + FUSED_PAD;
-    };
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int tx = wave % NT, rr = wave / NT;
-    const int x0 = tx * 256 + lane * 4;
+    FusedCtx<NT> c;
+    c.mask = mask;
+    c.rhs = rhs;
+    c.pin = pin;
+    c.pout = pout;
+    c.pmid = pmid;
+    c.lds = (FLUID_LDS float*)lds;
+    c.plane = g.plane;
+    c.Dl = g.Dl;
+    c.p_oob = p_air;
+    c.lane = threadIdx.x & 63;
+    // readfirstlane: tells hipcc the wave index (hence row, tile and halo role) is wave-uniform, so it
+    // lives in SGPRs and role tests become scalar branches instead of exec masking
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = wave % NT;
+    c.rr = wave / NT;
+    c.x0 = tx * 256 + c.lane * 4;
     const int y0 = blockIdx.y * TY;        // first output row
-    const int y = y0 - 1 + rr;             // this wavefront's row
-    const int zb = blockIdx.z * zchunk;
-    const int ze = min(zb + zchunk, g.Dl);
+    const int y = y0 - 1 + c.rr;           // this wavefront's row
+    c.zb = blockIdx.z * zchunk;
+    c.ze = min(c.zb + zchunk, g.Dl);
 
     {   // the whole group leaves if no brick it touches holds water (uniform: before any barrier)
         uint32_t any = 0;
         const int by0 = max(y0 - 1, 0) / BRICK_Y, by1 = min(y0 + TY, g.H - 1) / BRICK_Y;
-        const int bz0 = max(zb - 1, 0) / BRICK_Z, bz1 = min(ze, g.Dl - 1) / BRICK_Z;
+        const int bz0 = max(c.zb - 1, 0) / BRICK_Z, bz1 = min(c.ze, g.Dl - 1) / BRICK_Z;
         for (int bz = bz0; bz <= bz1; bz++)
             for (int by = by0; by <= by1; by++)
                 for (int bx = 0; bx < bk.nbx; bx++) any |= active[brick_index(bk, bx, by, bz)];
         if (any == 0) return;
     }
 
-    const float4 pa4 = make_float4(p_air, p_air, p_air, p_air);
-    const bool xin = x0 < g.W;
-    const bool row_in = xin && (unsigned)y < (unsigned)g.H;   // this lane's cells exist
-    const bool is_out_row = rr >= 1 && rr <= R - 2 && row_in;
-    const bool halo_lo = rr == 0, halo_hi = rr == R - 1;
-    const int yh = halo_lo ? y - 1 : y + 1;                    // outer neighbour row of a halo wave
-    const bool halo_in = (halo_lo || halo_hi) && xin && (unsigned)yh < (unsigned)g.H;
+    const bool xin = c.x0 < g.W;
+    c.row_in = xin && (unsigned)y < (unsigned)g.H;   // this lane's cells exist
+    c.is_out_row = c.rr >= 1 && c.rr <= R - 2 && c.row_in;
+    c.halo_lo = c.rr == 0;
+    c.halo_hi = c.rr == R - 1;
+    const int yh = c.halo_lo ? y - 1 : y + 1;        // outer neighbour row of a halo wavefront
+    const bool is_halo = c.halo_lo || c.halo_hi;
+    c.halo_in = is_halo && xin && (unsigned)yh < (unsigned)g.H;
+    c.wave_clean = __builtin_amdgcn_ballot_w64(!c.row_in || (is_halo && !c.halo_in)) == 0ull;
+    c.lane_mask = c.row_in ? 0xFFFFFFFFu : 0u;
     // in-plane byte offsets (safe addresses for lanes / rows outside the grid)
-    const unsigned xs = xin ? (unsigned)x0 : 0u;
-    const unsigned boff = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
-    const unsigned boff_h =
-        4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)yh < (unsigned)g.H) ? yh : 0));
+    const unsigned xs = xin ? (unsigned)c.x0 : 0u;
+    c.boff = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
+    c.boff_h = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)yh < (unsigned)g.H) ? yh : 0));
+    // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
+    c.xe = c.lane == 0 ? c.x0 - 1 : c.x0 + 4;
 
-    // Loads are unconditional, from a valid address (plane pointer redirected to plane 0 when the
-    // plane lies outside the grid), and the value is fixed up afterwards, late: a branch or a select
-    // directly on a load makes hipcc wait for it (vmcnt(0)) on the spot, which would expose the HBM
-    // latency in every step.
-    auto plane_ok = [&](int lz) { return lz >= 0 && lz < g.Dl; };  // whole-grid context
-    auto fix_j = [&](float4 v, bool ok, int lz) { return (ok && plane_ok(lz)) ? v : pa4; };
-    const uint32_t lane_mask = row_in ? 0xFFFFFFFFu : 0u;  // masks outside the grid read as 0
-    auto fix_m = [&](uint32_t m, int lz) { return plane_ok(lz) ? (m & lane_mask) : 0u; };
-
-    // pad cells of every LDS row: x = -1 and x = NT*256 read as p_air (outside the grid)
+    // pad cells of every LDS row: x = -1 and x = NT*256 read as p_oob (outside the grid)
     for (int i = threadIdx.x; i < 2 * 2 * R * 2 * FUSED_PAD; i += FUSED_THREADS) {
         const int side = i % (2 * FUSED_PAD), row = i / (2 * FUSED_PAD);
-        lds_f* base = (lds_f*)lds + row * RW;
+        FLUID_LDS float* base = c.lds + row * RW;
         base[side < FUSED_PAD ? side : RW - 2 * FUSED_PAD + side] = p_air;
     }
 
-    // registers: iterate j at planes zc-1, zc, zc+1 (+ zc+2 in flight); iterate j+1 at zc-2, zc-1
-    int zc = zb - 1;  // plane of iterate j+1 computed in the coming step
-    auto pl = [&](const float* base, int lz) {  // wave-uniform plane pointer, always inside the image
-        return base + (int64_t)(plane_ok(lz) ? lz : 0) * g.plane;
-    };
-    float4 jm = fix_j(ld_f4(pl(pin, zc - 1), boff), row_in, zc - 1);
-    float4 jc = fix_j(ld_f4(pl(pin, zc), boff), row_in, zc);
-    float4 jn = fix_j(ld_f4(pl(pin, zc + 1), boff), row_in, zc + 1), jnn;
-    float4 hc = fix_j(ld_f4(pl(pin, zc), boff_h), halo_in, zc), hn;  // halo waves: outer y row
-    float4 s_mm = pa4, s_m = pa4, s_c;
-    float4 b_c = ld_f4(pl(rhs, zc), boff), b_m = make_float4(0.f, 0.f, 0.f, 0.f), b_n;
-    uint32_t m_c = fix_m(ld_u32(mask + (pl(rhs, zc) - rhs), boff >> 2), zc), m_m = 0u, m_n;
-    // the address of the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4
-    const int xe = lane == 0 ? x0 - 1 : x0 + 4;
+    // prologue: the state a step with ring phase 0 and zc = zb - 1 expects
+    const float4 pa4 = make_float4(p_air, p_air, p_air, p_air);
+    FusedState st;
+    int zc = c.zb - 1;  // plane of iterate j+1 formed in the coming step
+    st.j[0] = c.fix_j(ld_f4(pin + c.plane_off(zc - 1), c.boff), c.row_in, zc - 1);
+    st.j[1] = c.fix_j(ld_f4(pin + c.plane_off(zc), c.boff), c.row_in, zc);
+    st.j[2] = ld_f4(pin + c.plane_off(zc + 1), c.boff);  // raw: fixed up by the first step
+    st.h[0] = ld_f4(pin + c.plane_off(zc), c.boff_h);
+    st.s[0] = pa4;
+    st.s[1] = pa4;
+    st.b[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.m[1] = MASK_DRY4;
+    st.b[2] = ld_f4(rhs + c.plane_off(zc), c.boff);
+    st.m[2] = ld_u32(mask + c.plane_off(zc), c.boff >> 2);
 
-    const int steps = ze - zb + 2;
-    for (int k = 0; k < steps; k++, zc++) {
-        const int buf = k & 1;
-        // ---- loads the next step needs (raw; fixed up at the rotation below)
-        jnn = ld_f4(pl(pin, zc + 2), boff);
-        hn = ld_f4(pl(pin, zc + 1), boff_h);
-        b_n = ld_f4(pl(rhs, zc + 1), boff);
-        m_n = ld_u32(mask + (pl(rhs, zc + 1) - rhs), boff >> 2);
-
-        // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
-        lds_f* jrow = row_ptr(buf, 0, rr);
-        lds_f* srow = row_ptr(buf, 1, rr);
-        lds_st4(jrow + x0, jc);
-        lds_st4(srow + x0, s_m);
-        __syncthreads();
-
-        // ---- stage 1: iterate j+1 at plane zc for this row
-        {
-            const bool wet = (m_c & 0x40404040u) != 0u;
-            s_c = jc;  // non-water (and out-of-grid) cells keep p_air
-            if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
-                const float4 ym = halo_lo ? hc : lds_ld4(row_ptr(buf, 0, halo_lo ? rr : rr - 1) + x0);
-                const float4 yp = halo_hi ? hc : lds_ld4(row_ptr(buf, 0, halo_hi ? rr : rr + 1) + x0);
-                const float e = jrow[xe];
-                const float left = from_lane_below(jc.w, e, lane);
-                const float right = from_lane_above(jc.x, e, lane);
-                float4 o;
-                o.x = canon_cell(b_c.x, m_c, 0, jc.y, yp.x, jn.x, left, ym.x, jm.x);
-                o.y = canon_cell(b_c.y, m_c, 8, jc.z, yp.y, jn.y, jc.x, ym.y, jm.y);
-                o.z = canon_cell(b_c.z, m_c, 16, jc.w, yp.z, jn.z, jc.y, ym.z, jm.z);
-                o.w = canon_cell(b_c.w, m_c, 24, right, yp.w, jn.w, jc.z, ym.w, jm.w);
-                s_c.x = (m_c & 0x40u) ? o.x : jc.x;
-                s_c.y = (m_c & 0x4000u) ? o.y : jc.y;
-                s_c.z = (m_c & 0x400000u) ? o.z : jc.z;
-                s_c.w = (m_c & 0x40000000u) ? o.w : jc.w;
-            }
-        }
-
-        // ---- stage 2: iterate j+2 at plane zc-1 from iterate j+1 at planes zc-2, zc-1, zc
-        const int zo = zc - 1;
-        if (zo >= zb && zo < ze && rr >= 1 && rr <= R - 2) {  // wave-uniform
-            const bool wet = is_out_row && (m_m & 0x40404040u) != 0u;
-            if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
-                const float4 ym = lds_ld4(row_ptr(buf, 1, rr - 1) + x0);
-                const float4 yp = lds_ld4(row_ptr(buf, 1, rr + 1) + x0);
-                const float e = srow[xe];
-                const float left = from_lane_below(s_m.w, e, lane);
-                const float right = from_lane_above(s_m.x, e, lane);
-                float4 o;
-                o.x = canon_cell(b_m.x, m_m, 0, s_m.y, yp.x, s_c.x, left, ym.x, s_mm.x);
-                o.y = canon_cell(b_m.y, m_m, 8, s_m.z, yp.y, s_c.y, s_m.x, ym.y, s_mm.y);
-                o.z = canon_cell(b_m.z, m_m, 16, s_m.w, yp.z, s_c.z, s_m.y, ym.z, s_mm.z);
-                o.w = canon_cell(b_m.w, m_m, 24, right, yp.w, s_c.w, s_m.z, ym.w, s_mm.w);
-                o.x = (m_m & 0x40u) ? o.x : s_m.x;
-                o.y = (m_m & 0x4000u) ? o.y : s_m.y;
-                o.z = (m_m & 0x400000u) ? o.z : s_m.z;
-                o.w = (m_m & 0x40000000u) ? o.w : s_m.w;
-                if (wet) {
-                    st_f4(pout + (int64_t)zo * g.plane, boff, o);
-                    if (pmid)  // the odd iterate, kept only by the last pair of a loop
-                        st_f4(pmid + (int64_t)zo * g.plane, boff, s_m);
-                }
-            }
-        }
-
-        // ---- rotate (and fix up what was loaded for the next step)
-        jm = jc;
-        jc = jn;
-        jn = fix_j(jnn, row_in, zc + 2);
-        hc = fix_j(hn, halo_in, zc + 1);
-        s_mm = s_m;
-        s_m = s_c;
-        b_m = b_c;
-        b_c = b_n;
-        m_m = m_c;
-        m_c = fix_m(m_n, zc + 1);
+    const int steps = c.ze - c.zb + 2;  // iterate j+1 at planes zb-1 .. ze, iterate j+2 one behind
+    for (int k = 0; k < steps; k += 4, zc += 4) {
+        fused_step<NT, 0>(c, st, zc);
+        if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
+        fused_step<NT, 1>(c, st, zc + 1);
+        if (k + 2 >= steps) break;
+        fused_step<NT, 2>(c, st, zc + 2);
+        if (k + 3 >= steps) break;
+        fused_step<NT, 3>(c, st, zc + 3);
     }
 }
 

@@ -36,9 +36,20 @@ __device__ __forceinline__ float from_lane_above(float v, float edge, int lane) 
     return lane == 63 ? edge : __int_as_float(r);
 }
 
-// one water cell: b = b_i, bits [sh, sh+6) of m = its non-solid-neighbour flags, q* = working
-// pressures of the six neighbours (solid ones hold +0.0f)
-__device__ __forceinline__ float canon_cell(float b, uint32_t m, int sh, float qxp, float qyp,
+// Mask byte of a cell (k12_prepare): the number of its non-solid neighbours, 0..6, if the cell is
+// WATER (aii of pressure.comp:53-61), MASK_DRY otherwise.
+constexpr uint32_t MASK_DRY = 8u;
+constexpr uint32_t MASK_DRY4 = 0x08080808u;
+// any of the four cells packed in a mask word is water
+__device__ __forceinline__ bool mask_any_water(uint32_t m) { return (m & MASK_DRY4) != MASK_DRY4; }
+// cell i (0..3) of a mask word is water
+__device__ __forceinline__ bool mask_is_water(uint32_t m, int i) {
+    return ((m >> (8 * i)) & MASK_DRY) == 0u;
+}
+
+// one water cell: b = b_i, byte i of m = its mask byte, q* = working pressures of the six
+// neighbours (solid ones hold +0.0f, so subtracting them is the shader's "skip")
+__device__ __forceinline__ float canon_cell(float b, uint32_t m, int i, float qxp, float qyp,
                                             float qzp, float qxm, float qym, float qzm) {
     float s = b;
     s = s - qxp;  // pressure.comp:56-61 order: +x, +y, +z, -x, -y, -z
@@ -47,7 +58,7 @@ __device__ __forceinline__ float canon_cell(float b, uint32_t m, int sh, float q
     s = s - qxm;
     s = s - qym;
     s = s - qzm;
-    const float aii = (float)__builtin_popcount((m >> sh) & 63u);
+    const float aii = (float)((m >> (8 * i)) & 0xFFu);  // v_cvt_f32_ubyte<i>
     return -s / aii;  // :62
 }
 

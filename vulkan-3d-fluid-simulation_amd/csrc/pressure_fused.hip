@@ -2,9 +2,64 @@
 #include "kernels_pressure_fused.h"
 #include "pressure_api.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 namespace fluid {
 
 bool k12_canon2_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 1024 && g.z0 == 0 && g.Dl == g.Dg; }
+
+// z-chunk choice.  One 16-wavefront workgroup occupies a CU, so a launch runs in "rounds" of one
+// workgroup per CU and a tile count just above a multiple of the CU count wastes most of a round.
+// Estimate the makespan of every candidate chunk length by dealing the tiles (cost = planes + 2
+// pipeline steps + a fixed start-up) to the CUs in launch order, and take the best.  Host
+// arithmetic, cached per geometry.
+static int pick_zchunk(int row_groups, int depth, int cus) {
+    static int c_groups = -1, c_depth = -1, c_cus = -1, c_result = 0;
+    if (row_groups == c_groups && depth == c_depth && cus == c_cus) return c_result;
+    const double startup = 3.0;
+    double best_cost = 1e300;
+    int best = std::min(depth, 32);
+    for (int zc = std::min(depth, 16); zc <= std::min(depth, 128); zc++) {
+        const int nz = (depth + zc - 1) / zc;
+        std::vector<double> busy(cus, 0.0);  // min-heap by finish time
+        auto cmp = [](double a, double b) { return a > b; };
+        std::make_heap(busy.begin(), busy.end(), cmp);
+        double makespan = 0.0;
+        for (int z = 0; z < nz; z++) {
+            const int planes = std::min(zc, depth - z * zc);
+            const double cost = planes + 2 + startup;
+            for (int y = 0; y < row_groups; y++) {
+                std::pop_heap(busy.begin(), busy.end(), cmp);
+                busy.back() += cost;
+                makespan = std::max(makespan, busy.back());
+                std::push_heap(busy.begin(), busy.end(), cmp);
+            }
+        }
+        if (makespan < best_cost) {
+            best_cost = makespan;
+            best = zc;
+        }
+    }
+    c_groups = row_groups;
+    c_depth = depth;
+    c_cus = cus;
+    c_result = best;
+    return best;
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            n <= 0)
+            n = 256;
+    }
+    return n;
+}
 
 template <int NT>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
@@ -20,9 +75,8 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     }
     constexpr int TY = FUSED_WAVES / NT - 2;
     const int by = (g.H + TY - 1) / TY;
-    int zchunk = g.Dl;
-    while (zchunk > 32 && (int64_t)by * ((g.Dl + zchunk - 1) / zchunk) < 1024)
-        zchunk = (zchunk + 1) / 2;
+    int zchunk = pick_zchunk(by, g.Dl, cu_count());
+    if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
     const dim3 grid(1, by, (g.Dl + zchunk - 1) / zchunk);
     BrickK bk;
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
