@@ -168,7 +168,7 @@ def main():
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"12_solve_pressure loop, {w}x{h}x{d} full-fluid grid, "
                                        f"{args.iters} Jacobi iterations per step, Z slabs over "
-                                       f"{world} GPUs, 1-plane halo exchange per sweep (RCCL)",
+                                       f"{world} GPUs, halo exchange over RCCL Send/Recv",
                            "grid": [w, h, d], "jacobi_iterations": args.iters,
                            "parallelism": f"zslab{world}"},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -272,18 +272,27 @@ int fluid_reset_timing(fluid_ctx* ctx);
  * 0 … z_count-1 = owned planes, z_count = upper ghost plane.  Planes are contiguous in memory.    */
 int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** device_ptr,
                           uint64_t* bytes);
-/* The loop section in explicit form, for callers that must act between sweeps (halo exchange):
- *   begin : build the solver's working buffers from PRESSURES_1 (iterate 0 -> working buffer 0)
- *   sweep : dispatch k of the loop: working buffer k%2 -> working buffer (k+1)%2
- *   end   : write the last two iterates into the water cells of PRESSURES_1 (even) / PRESSURES_2 (odd)
- * begin; sweep(0..N-1); end(N) equals fluid_run_section_loop(FLUID_SEC_12_SOLVE_PRESSURE, N).  Between
- * calls the caller exchanges the boundary planes of the buffer just written (work_plane_ptr, same
- * plane numbering as fluid_image_plane_ptr).  Needs fluid_size.x % 4 == 0, else FLUID_ERR_UNSUPPORTED
- * (then loop over fluid_run_pressure_dispatch and exchange the image planes instead). */
+/* The loop section in explicit form, for callers that must act between launches (halo exchange):
+ *   begin   : build the solver's working data from CELL_TYPES / DIVERGENCES / PRESSURES_1
+ *             (iterate 0 -> working buffer 0)
+ *   advance : 1 sweep, or 2 sweeps in one pass over HBM where fluid_pressure_loop_max_sweeps() says
+ *             2; `keep_intermediate` = also keep the odd iterate of a pair (needed for the last pair
+ *             of an even-length loop); *written_buffer = working buffer (0..2) now holding the newest
+ *             iterate
+ *   end     : write the last two iterates into the water cells of PRESSURES_1 (even) / PRESSURES_2 (odd)
+ * begin; advance...; end equals fluid_run_section_loop(FLUID_SEC_12_SOLVE_PRESSURE, N) for the same
+ * number of sweeps.  On a Z-slab context the caller exchanges, after begin, one boundary plane of the
+ * mask (buffer 3) and of b_i (buffer 4) and TWO boundary planes of working buffer 0 with each
+ * neighbour, and after every advance two boundary planes of the buffer just written
+ * (fluid_pressure_loop_plane_ptr: planes -2,-1 / Dl,Dl+1 are the ghost planes of buffers 0..2,
+ * -1 / Dl those of buffers 3 and 4).  Needs fluid_size.x % 4 == 0, else FLUID_ERR_UNSUPPORTED (then
+ * loop over fluid_run_pressure_dispatch and exchange the image planes instead). */
 int fluid_pressure_loop_begin(fluid_ctx* ctx);
-int fluid_pressure_loop_sweep(fluid_ctx* ctx, uint32_t k);
-int fluid_pressure_loop_end(fluid_ctx* ctx, uint32_t iterations);
-int fluid_pressure_work_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
+int fluid_pressure_loop_max_sweeps(fluid_ctx* ctx);
+int fluid_pressure_loop_advance(fluid_ctx* ctx, uint32_t sweeps, int keep_intermediate,
+                                int* written_buffer);
+int fluid_pressure_loop_end(fluid_ctx* ctx);
+int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes);
 
 /* Tell the engine that the caller wrote device memory of `image_id` through a pointer obtained

@@ -69,11 +69,12 @@ def test_params_default_c_and_python_agree_and_match_reference_constants():
 def test_required_arena_bytes_is_host_arithmetic():
     p = default_params(64, 64, 64, 1000)
     n = fluid_amd.FluidEngine.required_arena_bytes(p, 1000)
-    cells_with_ghosts = 64 * 64 * 66
-    # 50 B/cell of attachments + 17 B/cell of internal solver data (neighbour mask,
-    # b_i and three working buffers of the pressure loop) + particles, each block 4-KiB aligned
-    assert n >= cells_with_ghosts * 67 + 1000 * 16
-    assert n < cells_with_ghosts * 67 + 1000 * 16 + 20 * 4096
+    plane = 64 * 64
+    # 50 B/cell of attachments and 5 B/cell of solver data (neighbour mask, b_i) with
+    # one ghost plane per side, three 4-byte working buffers of the pressure loop with two ghost planes
+    # per side, particles; each block 4-KiB aligned
+    want = plane * 66 * 55 + plane * 68 * 12 + 1000 * 16
+    assert want <= n < want + 20 * 4096
     half = fluid_amd.FluidEngine.required_arena_bytes(p, 1000, slab=(0, 32))
     assert half < n
     bad = default_params(64, 64, 64, 0)

@@ -62,8 +62,13 @@ def _worker(rank, world, port, size, iters, seed, variant, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,variant", [(2, (64, 24, 20), 6, 2), (3, (260, 9, 11), 5, 3),
-                                                      (2, (17, 9, 8), 4, 0)])
+@pytest.mark.parametrize("world,size,iters,variant", [
+    (2, (64, 24, 20), 6, 0),    # working-buffer loop, two sweeps per exchange
+    (3, (260, 9, 11), 5, 0),    # 3 slabs of 4/4/3 planes, odd iteration count (pair, pair, single)
+    (3, (256, 12, 13), 8, 7),   # explicit fast-path kernel option
+    (2, (64, 24, 20), 7, 2),    # general kernel on the images, one plane per sweep
+    (2, (17, 9, 8), 4, 0),      # width not a multiple of 4: falls back to the images as well
+])
 def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, tmp_path):
     import torch.multiprocessing as mp
 

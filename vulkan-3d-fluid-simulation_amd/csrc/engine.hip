@@ -82,12 +82,16 @@ struct fluid_ctx {
     // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, (Dl+2) planes each
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
-    uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, (Dl+2) planes each
+    uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, (Dl+4) planes each: two ghost
+                                          // planes per side (two sweeps per halo exchange)
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
     bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
     bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
-    // explicit loop (fluid_pressure_loop_begin / _sweep / _end)
+    // state of an open loop (fluid_pressure_loop_begin / _advance / _end, and run_fast_loop)
     bool loop_open = false;
+    int loop_cur = 0;        // working buffer of the newest iterate
+    int loop_prev = -1;      // working buffer of the iterate before it, -1 = not kept
+    uint32_t loop_k = 0;     // index of the newest iterate
 
     bool timing = false;
     std::vector<TimerSlot> pending;
@@ -114,7 +118,9 @@ struct fluid_ctx {
     float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
     uint8_t* mask0() const { return arena + mask_offset + (uint64_t)g.plane; }
     float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + g.plane; }
-    float* work0(int i) const { return reinterpret_cast<float*>(arena + work_offset[i]) + g.plane; }
+    float* work0(int i) const {  // owned plane 0
+        return reinterpret_cast<float*>(arena + work_offset[i]) + 2 * g.plane;
+    }
     uint8_t* bricks() const { return arena + active_offset; }
     // bookkeeping for the fast path: call whenever an image's device contents change
     void touched(int image) {
@@ -242,7 +248,7 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     off = align_up(off + L.active_bytes, kAlign);
     for (int i = 0; i < 3; i++) {
         L.work_offset[i] = off;
-        off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
+        off = align_up(off + plane * (uint64_t)(dl + 4) * 4, kAlign);
     }
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
@@ -398,28 +404,19 @@ int ensure_prepared(fluid_ctx* c) {
     c->mask_valid = c->rhs_valid = true;
     return FLUID_OK;
 }
-// ghost planes that hold a neighbouring slab's cells are part of the working buffers too
-void work_plane_range(const fluid_ctx* c, int& lz0, int& n) {
-    const GridK& g = c->g;
-    const bool lo = g.z0 > 0, hi = g.z0 + g.Dl < g.Dg;
-    lz0 = lo ? -1 : 0;
-    n = g.Dl + (lo ? 1 : 0) + (hi ? 1 : 0);
-}
+// Import / background cover the owned planes; ghost planes of the working buffers are filled by the
+// caller's halo exchange (whole planes, so their non-water constants arrive with them).
 int import_pressures(fluid_ctx* c, int image, int w) {
-    int lz0, n;
-    work_plane_range(c, lz0, n);
     k12_launch_import(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
-                      c->work0(w), c->g, c->pk, lz0, n);
+                      c->work0(w), c->g, c->pk, 0, c->g.Dl);
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[w] = true;
     return FLUID_OK;
 }
 int ensure_background(fluid_ctx* c, int w) {
     if (c->bg_valid[w]) return FLUID_OK;
-    int lz0, n;
-    work_plane_range(c, lz0, n);
     k12_launch_background(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->work0(w), c->g,
-                          c->pk, lz0, n);
+                          c->pk, 0, c->g.Dl);
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[w] = true;
     return FLUID_OK;
@@ -454,52 +451,77 @@ int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
     return FLUID_OK;
 }
 
-// FlowLoopPushConstantSection on working buffers: import PRESSURES_1, N sweeps, export the last
-// two iterates.  Iterate k lives in a working buffer; dispatch k of the reference maps iterate k
-// (read from PRESSURES_1 if k is even, else PRESSURES_2) to iterate k+1 in the other image.
-int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
-    if (iterations == 0) return FLUID_OK;
+// ---- the loop as a small state machine: begin (import) / advance by 1 or 2 sweeps / end (export) ----
+// Iterate k lives in a working buffer; dispatch k of the reference maps iterate k (read from
+// PRESSURES_1 if k is even, else PRESSURES_2) to iterate k+1 in the other image.
+int loop_begin(fluid_ctx* c) {
     int rc = ensure_prepared(c);
-    if (rc) return rc;
-    rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);  // iterate 0 -> work[0]
-    if (rc) return rc;
-    const bool fuse = k12_canon2_supports(c->g) && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
-    int cur = 0;          // buffer of the newest iterate
-    int prev = -1;        // buffer of the iterate before it (valid when >= 0)
-    uint32_t k = 0;       // index of the newest iterate
-    auto other = [](int a, int b) {  // a working buffer that is neither a nor b
-        for (int i = 0; i < 3; i++)
-            if (i != a && i != b) return i;
-        return -1;
-    };
-    if (fuse) {
-        // Two sweeps per pass over HBM; only the last pair of an even-length loop also writes the
-        // odd iterate N-1 (which 13_fix_divergence will read from PRESSURES_2).
-        const uint32_t pairs = iterations / 2;
-        for (uint32_t p = 0; p < pairs && rc == FLUID_OK; p++) {
-            const bool need_mid = (p + 1 == pairs) && (iterations % 2u == 0u);
-            const int dst = other(cur, cur);
-            const int mid = need_mid ? other(cur, dst) : -1;
-            rc = ensure_background(c, dst);
-            if (rc == FLUID_OK && mid >= 0) rc = ensure_background(c, mid);
-            if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid);
-            prev = mid;
-            cur = dst;
-            k += 2;
-        }
-    }
-    while (k < iterations && rc == FLUID_OK) {  // single sweeps: the whole loop, or an odd tail
-        const int dst = other(cur, prev >= 0 ? prev : cur);
+    if (rc == FLUID_OK) rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);  // iterate 0 -> work[0]
+    c->loop_open = rc == FLUID_OK;
+    c->loop_cur = 0;
+    c->loop_prev = -1;
+    c->loop_k = 0;
+    return rc;
+}
+// a working buffer that is neither a nor b
+int other_buffer(int a, int b) {
+    for (int i = 0; i < 3; i++)
+        if (i != a && i != b) return i;
+    return -1;
+}
+// Advance by one sweep, or by two in one pass (kernels_pressure_fused.h).  With two, the
+// intermediate iterate is kept only when `keep_mid` (the last pair of an even-length loop: iterate
+// N-1 is what PRESSURES_2 must hold).  Returns the buffer written with the newest iterate.
+int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
+    int rc = FLUID_OK;
+    const int cur = c->loop_cur;
+    if (sweeps == 2) {
+        const int dst = other_buffer(cur, cur);
+        const int mid = keep_mid ? other_buffer(cur, dst) : -1;
+        rc = ensure_background(c, dst);
+        if (rc == FLUID_OK && mid >= 0) rc = ensure_background(c, mid);
+        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid);
+        c->loop_prev = mid;
+        c->loop_cur = dst;
+        c->loop_k += 2;
+    } else {
+        const int dst = other_buffer(cur, c->loop_prev >= 0 ? c->loop_prev : cur);
         rc = ensure_background(c, dst);
         if (rc == FLUID_OK) rc = launch_work_sweep(c, cur, dst);
-        prev = cur;
-        cur = dst;
-        k++;
+        c->loop_prev = cur;
+        c->loop_cur = dst;
+        c->loop_k += 1;
+    }
+    if (written) *written = c->loop_cur;
+    return rc;
+}
+int loop_end(fluid_ctx* c) {
+    c->loop_open = false;
+    c->pressure_dispatch_index = c->loop_k;
+    if (c->loop_k == 0) return FLUID_OK;
+    // iterates N and N-1: the even one belongs in PRESSURES_1, the odd one in PRESSURES_2
+    const bool n_even = (c->loop_k % 2u) == 0u;
+    return export_pressures(c, n_even ? c->loop_cur : c->loop_prev,
+                            n_even ? c->loop_prev : c->loop_cur);
+}
+bool fuse_enabled(const fluid_ctx* c) {
+    return k12_canon2_supports(c->g) && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
+}
+
+// FlowLoopPushConstantSection on working buffers (single context, no halo exchange)
+int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
+    if (iterations == 0) return FLUID_OK;
+    int rc = loop_begin(c);
+    const bool fuse = fuse_enabled(c) && !c->is_slab;  // a slab needs its halos between launches
+    while (rc == FLUID_OK && c->loop_k < iterations) {
+        const uint32_t left = iterations - c->loop_k;
+        if (fuse && left >= 2)
+            rc = loop_advance(c, 2, left == 2, nullptr);
+        else
+            rc = loop_advance(c, 1, false, nullptr);
     }
     if (rc) return rc;
-    // iterate N and N-1: the even one belongs in PRESSURES_1, the odd one in PRESSURES_2
-    const bool n_even = (iterations % 2u) == 0u;
-    return export_pressures(c, n_even ? cur : prev, n_even ? prev : cur);
+    return loop_end(c);
 }
 
 int slab_unsupported(fluid_ctx* c, const char* what) {
@@ -992,7 +1014,7 @@ int fluid_run_pressure_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {
     return rc ? rc : rc2;
 }
 
-// ---- the loop section in explicit form (multi-GPU: the caller exchanges halos between sweeps) ----
+// ---- the loop section in explicit form (multi-GPU: the caller exchanges halos between launches) ----
 int fluid_pressure_loop_begin(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1000,45 +1022,54 @@ int fluid_pressure_loop_begin(fluid_ctx* c) {
         return c->fail(FLUID_ERR_UNSUPPORTED,
                        "the working-buffer loop needs fluid_size.x %% 4 == 0 (and pressure kernel "
                        "option 0 or >= 5); use fluid_run_pressure_dispatch per sweep instead");
-    int rc = ensure_prepared(c);
-    if (rc == FLUID_OK) rc = import_pressures(c, FLUID_IMG_PRESSURES_1, 0);
-    if (rc == FLUID_OK) rc = ensure_background(c, 1);
-    c->loop_open = rc == FLUID_OK;
-    return rc;
+    return loop_begin(c);
 }
 
-int fluid_pressure_loop_sweep(fluid_ctx* c, uint32_t k) {
+int fluid_pressure_loop_max_sweeps(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    return fuse_enabled(c) ? 2 : 1;
+}
+
+int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermediate,
+                                int* written_buffer) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
+    if (sweeps != 1 && !(sweeps == 2 && fuse_enabled(c)))
+        return c->fail(FLUID_ERR_INVALID_ARG, "cannot advance by %u sweeps in one launch", sweeps);
     HIP_TRY(c, hipSetDevice(c->device));
     SectionTimer tm{c};
     int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
     if (rc) return rc;
-    rc = launch_work_sweep(c, (int)(k & 1u), (int)((k + 1u) & 1u));
+    rc = loop_advance(c, sweeps, keep_intermediate != 0, written_buffer);
     int rc2 = tm.end();
+    if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && sweeps == 2)
+        c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += 1;  // count sweeps
     return rc ? rc : rc2;
 }
 
-int fluid_pressure_loop_end(fluid_ctx* c, uint32_t iterations) {
+int fluid_pressure_loop_end(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
     HIP_TRY(c, hipSetDevice(c->device));
-    c->loop_open = false;
-    c->pressure_dispatch_index = iterations;
-    if (iterations == 0) return FLUID_OK;
-    // iterate k lives in work[k % 2]: the even iterate goes to PRESSURES_1, the odd to PRESSURES_2
-    return export_pressures(c, 0, 1);
+    return loop_end(c);
 }
 
-int fluid_pressure_work_plane_ptr(fluid_ctx* c, int which, int32_t plane, void** device_ptr,
+// which: 0..2 = working pressure buffers (planes -2 .. Dl+1), 3 = mask (planes -1 .. Dl, 1 byte per
+// cell), 4 = b_i (planes -1 .. Dl)
+int fluid_pressure_loop_plane_ptr(fluid_ctx* c, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
-    if (which < 0 || which > 1) return c->fail(FLUID_ERR_INVALID_ARG, "working buffer %d", which);
-    if (plane < -1 || plane > c->g.Dl)
-        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [-1, %d]", plane, c->g.Dl);
-    const uint64_t pb = (uint64_t)c->g.plane * 4;
-    *device_ptr = c->arena + c->work_offset[which] + (uint64_t)(plane + 1) * pb;
+    if (which < 0 || which > 4) return c->fail(FLUID_ERR_INVALID_ARG, "loop buffer %d", which);
+    const int ghost = which <= 2 ? 2 : 1;
+    if (plane < -ghost || plane >= c->g.Dl + ghost)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -ghost,
+                       c->g.Dl + ghost);
+    const uint64_t elem = which == 3 ? 1 : 4;
+    const uint64_t pb = (uint64_t)c->g.plane * elem;
+    const uint64_t base = which <= 2 ? c->work_offset[which]
+                                     : (which == 3 ? c->mask_offset : c->rhs_offset);
+    *device_ptr = c->arena + base + (uint64_t)(plane + ghost) * pb;
     *bytes = pb;
     return FLUID_OK;
 }

@@ -20,8 +20,11 @@
 //     the adjacent lanes (DPP wave shifts); one s_barrier per plane, LDS double-buffered;
 //   * rows 0 and R-1 of the group only compute iterate j+1 (halo rows); their outer y neighbour
 //     row of iterate j is loaded from global memory.
-// Works on the loop's internal working buffers (kernels_pressure.h) of a whole-grid context: planes
-// and rows outside the grid are the constant p_oob for both iterates.
+// Works on the loop's internal working buffers (kernels_pressure.h); rows and planes outside the grid
+// are the constant p_oob for both iterates.  On a Z-slab context the working buffers carry TWO ghost
+// planes per side with the neighbouring slab's cells of iterate j (and mask / b_i one): iterate j+1 is
+// then formed on the first ghost plane as well, so the owned planes of iterate j+2 are exact and the
+// slabs exchange two planes every two sweeps.
 #pragma once
 
 #include "pressure_common.h"
@@ -78,6 +81,9 @@ struct FusedCtx {
     FLUID_LDS float* lds;
     int64_t plane;
     int Dl, zb, ze;
+    int jlo, jhi;  // local planes [jlo, jhi) of the working buffers hold cells of the grid: the owned
+                   // planes plus two ghost planes per side where a neighbouring slab exists
+    int mlo, mhi;  // same for mask / b_i (one ghost plane per side)
     int lane, rr, x0, xe;
     unsigned boff, boff_h;
     float p_oob;
@@ -88,21 +94,25 @@ struct FusedCtx {
     __device__ __forceinline__ FLUID_LDS float* row_ptr(int buf, int arr, int row) const {
         return lds + ((buf * 2 + arr) * R + row) * RW + FUSED_PAD;
     }
-    __device__ __forceinline__ bool plane_ok(int lz) const { return lz >= 0 && lz < Dl; }
+    __device__ __forceinline__ bool j_ok(int lz) const { return lz >= jlo && lz < jhi; }
+    __device__ __forceinline__ bool m_ok(int lz) const { return lz >= mlo && lz < mhi; }
     // element offset of plane lz, redirected to plane 0 when lz is outside the grid: loads are always
     // issued, from a valid address, and the value is replaced later (fix_*).  A branch or a select
     // directly on a load makes hipcc wait for it (vmcnt(0)) on the spot.
-    __device__ __forceinline__ int64_t plane_off(int lz) const {
-        return plane_ok(lz) ? (int64_t)lz * plane : (int64_t)0;
+    __device__ __forceinline__ int64_t j_off(int lz) const {
+        return j_ok(lz) ? (int64_t)lz * plane : (int64_t)0;
+    }
+    __device__ __forceinline__ int64_t m_off(int lz) const {
+        return m_ok(lz) ? (int64_t)lz * plane : (int64_t)0;
     }
     __device__ __forceinline__ float4 fix_j(float4 v, bool ok, int lz) const {
-        if (wave_clean && plane_ok(lz)) return v;  // wave-uniform: the common case costs nothing
+        if (wave_clean && j_ok(lz)) return v;  // wave-uniform: the common case costs nothing
         const float4 pa4 = make_float4(p_oob, p_oob, p_oob, p_oob);
-        return (ok && plane_ok(lz)) ? v : pa4;
+        return (ok && j_ok(lz)) ? v : pa4;
     }
     __device__ __forceinline__ uint32_t fix_m(uint32_t m, int lz) const {
-        if (wave_clean && plane_ok(lz)) return m;
-        return plane_ok(lz) ? ((m & lane_mask) | (MASK_DRY4 & ~lane_mask)) : MASK_DRY4;
+        if (wave_clean && m_ok(lz)) return m;
+        return m_ok(lz) ? ((m & lane_mask) | (MASK_DRY4 & ~lane_mask)) : MASK_DRY4;
     }
 };
 
@@ -121,11 +131,11 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
     const uint32_t m_m = st.m[(I + 1) & 3];
 
     // ---- loads the next step needs (raw; fixed up at the end of this step)
-    const int64_t o1 = c.plane_off(zc + 1), o2 = c.plane_off(zc + 2);
+    const int64_t o1 = c.j_off(zc + 1), o2 = c.j_off(zc + 2), a1 = c.m_off(zc + 1);
     st.j[(I + 3) & 3] = ld_f4(c.pin + o2, c.boff);
     st.h[(I + 1) & 1] = ld_f4(c.pin + o1, c.boff_h);
-    st.b[(I + 3) & 3] = ld_f4(c.rhs + o1, c.boff);
-    st.m[(I + 3) & 3] = ld_u32(c.mask + o1, c.boff >> 2);
+    st.b[(I + 3) & 3] = ld_f4(c.rhs + a1, c.boff);
+    st.m[(I + 3) & 3] = ld_u32(c.mask + a1, c.boff >> 2);
 
     // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
     FLUID_LDS float* jrow = c.row_ptr(buf, 0, c.rr);
@@ -208,6 +218,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.lds = (FLUID_LDS float*)lds;
     c.plane = g.plane;
     c.Dl = g.Dl;
+    {   // a neighbouring slab below / above: its boundary planes sit in this context's ghost planes
+        const bool lo = g.z0 > 0, hi = g.z0 + g.Dl < g.Dg;
+        c.jlo = lo ? -2 : 0;
+        c.jhi = g.Dl + (hi ? 2 : 0);
+        c.mlo = lo ? -1 : 0;
+        c.mhi = g.Dl + (hi ? 1 : 0);
+    }
     c.p_oob = p_air;
     c.lane = threadIdx.x & 63;
     // readfirstlane: tells hipcc the wave index (hence row, tile and halo role) is wave-uniform, so it
@@ -259,16 +276,16 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const float4 pa4 = make_float4(p_air, p_air, p_air, p_air);
     FusedState st;
     int zc = c.zb - 1;  // plane of iterate j+1 formed in the coming step
-    st.j[0] = c.fix_j(ld_f4(pin + c.plane_off(zc - 1), c.boff), c.row_in, zc - 1);
-    st.j[1] = c.fix_j(ld_f4(pin + c.plane_off(zc), c.boff), c.row_in, zc);
-    st.j[2] = ld_f4(pin + c.plane_off(zc + 1), c.boff);  // raw: fixed up by the first step
-    st.h[0] = ld_f4(pin + c.plane_off(zc), c.boff_h);
+    st.j[0] = c.fix_j(ld_f4(pin + c.j_off(zc - 1), c.boff), c.row_in, zc - 1);
+    st.j[1] = c.fix_j(ld_f4(pin + c.j_off(zc), c.boff), c.row_in, zc);
+    st.j[2] = ld_f4(pin + c.j_off(zc + 1), c.boff);  // raw: fixed up by the first step
+    st.h[0] = ld_f4(pin + c.j_off(zc), c.boff_h);
     st.s[0] = pa4;
     st.s[1] = pa4;
     st.b[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     st.m[1] = MASK_DRY4;
-    st.b[2] = ld_f4(rhs + c.plane_off(zc), c.boff);
-    st.m[2] = ld_u32(mask + c.plane_off(zc), c.boff >> 2);
+    st.b[2] = ld_f4(rhs + c.m_off(zc), c.boff);
+    st.m[2] = ld_u32(mask + c.m_off(zc), c.boff >> 2);
 
     const int steps = c.ze - c.zb + 2;  // iterate j+1 at planes zb-1 .. ze, iterate j+2 one behind
     for (int k = 0; k < steps; k += 4, zc += 4) {

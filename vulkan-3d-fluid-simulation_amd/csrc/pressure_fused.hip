@@ -8,7 +8,7 @@
 
 namespace fluid {
 
-bool k12_canon2_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 1024 && g.z0 == 0 && g.Dl == g.Dg; }
+bool k12_canon2_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 1024 && g.Dl >= 2; }
 
 // z-chunk choice.  One 16-wavefront workgroup occupies a CU, so a launch runs in "rounds" of one
 // workgroup per CU and a tile count just above a multiple of the CU count wastes most of a round.

@@ -61,8 +61,8 @@ EXPORTED_SYMBOLS = [
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
-    "fluid_pressure_loop_begin", "fluid_pressure_loop_sweep", "fluid_pressure_loop_end",
-    "fluid_pressure_work_plane_ptr",
+    "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
+    "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_get_geometry", "fluid_set_option",
 ]
 
@@ -133,9 +133,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
-        "fluid_pressure_loop_sweep": (C.c_int, [vp, u32]),
-        "fluid_pressure_loop_end": (C.c_int, [vp, u32]),
-        "fluid_pressure_work_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
+        "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
+        "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
+        "fluid_pressure_loop_end": (C.c_int, [vp]),
+        "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
                                                     C.POINTER(u64)]),
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
@@ -338,18 +339,31 @@ class FluidEngine:
         return {name: self.section_time_ms(i) for i, name in enumerate(SECTION_NAMES)}
 
     # -- multi-GPU plumbing ---------------------------------------------------------------------------
+    # the loop section in explicit form (fluid_pressure_loop_*)
+    LOOP_MASK, LOOP_RHS = 3, 4  # buffer ids of fluid_pressure_loop_plane_ptr besides 0..2
+
     def pressure_loop_begin(self):
         self._check(self._lib.fluid_pressure_loop_begin(self._h))
 
-    def pressure_loop_sweep(self, k: int):
-        self._check(self._lib.fluid_pressure_loop_sweep(self._h, k))
+    def pressure_loop_max_sweeps(self) -> int:
+        n = self._lib.fluid_pressure_loop_max_sweeps(self._h)
+        if n < 0:
+            self._check(n)
+        return n
 
-    def pressure_loop_end(self, iterations: int):
-        self._check(self._lib.fluid_pressure_loop_end(self._h, iterations))
+    def pressure_loop_advance(self, sweeps: int, keep_intermediate: bool = False) -> int:
+        written = C.c_int(-1)
+        self._check(self._lib.fluid_pressure_loop_advance(self._h, sweeps,
+                                                          1 if keep_intermediate else 0,
+                                                          C.byref(written)))
+        return int(written.value)
 
-    def pressure_work_plane_ptr(self, which: int, plane: int):
+    def pressure_loop_end(self):
+        self._check(self._lib.fluid_pressure_loop_end(self._h))
+
+    def pressure_loop_plane_ptr(self, which: int, plane: int):
         ptr, nbytes = C.c_void_p(), C.c_uint64()
-        self._check(self._lib.fluid_pressure_work_plane_ptr(self._h, which, plane, C.byref(ptr),
+        self._check(self._lib.fluid_pressure_loop_plane_ptr(self._h, which, plane, C.byref(ptr),
                                                             C.byref(nbytes)))
         return int(ptr.value), int(nbytes.value)
 

@@ -112,13 +112,6 @@ class GpuSlabCompute:
         view = self.arena[off:off + nbytes]
         return view.view(self.torch.float32) if as_float else view
 
-    def work_plane(self, which: int, local_z: int):
-        """Plane of the buffer that holds the iterates of parity `which` during a loop: the
-        engine's working buffer (fast path) or the pressure image itself."""
-        if self.fast:
-            return self._view(*self.engine.pressure_work_plane_ptr(which, local_z), True)
-        return self.plane(E.PRESSURES_1 if which == 0 else E.PRESSURES_2, local_z)
-
     def upload(self, image_id: int, array: np.ndarray):
         self.engine.upload_image(image_id, array)
 
@@ -129,20 +122,37 @@ class GpuSlabCompute:
         self.engine.run_section("12a_clear_pressures_1")
         self.engine.run_section("12b_clear_pressures_2")
 
-    # the loop section in explicit form (include/fluid_engine.h: fluid_pressure_loop_*)
+    # ---- the loop section in explicit form (include/fluid_engine.h: fluid_pressure_loop_*) ----
+    # A "loop buffer" is anything the slabs must exchange boundary planes of.  planes(buf, first, n)
+    # returns n consecutive local planes starting at `first` as one flat tensor (contiguous memory).
     def loop_begin(self):
+        """Returns [(buffer, ghost_width)] to exchange once, before the first advance."""
         if self.fast:
             self.engine.pressure_loop_begin()
+            return [(self.engine.LOOP_MASK, 1), (self.engine.LOOP_RHS, 1), (0, 2)]
+        return [(0, 1), (1, 1)]  # the two pressure images themselves
 
-    def loop_sweep(self, k: int):
-        if self.fast:
-            self.engine.pressure_loop_sweep(k)
-        else:
-            self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
+    def loop_max_sweeps(self) -> int:
+        return self.engine.pressure_loop_max_sweeps() if self.fast else 1
 
-    def loop_end(self, iterations: int):
+    def loop_advance(self, k: int, sweeps: int, keep_mid: bool):
+        """Sweeps k .. k+sweeps-1.  Returns (buffer written, ghost width to exchange)."""
         if self.fast:
-            self.engine.pressure_loop_end(iterations)
+            return self.engine.pressure_loop_advance(sweeps, keep_mid), 2
+        assert sweeps == 1
+        self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
+        return (k + 1) % 2, 1
+
+    def loop_end(self):
+        if self.fast:
+            self.engine.pressure_loop_end()
+
+    def planes(self, buf: int, first: int, count: int):
+        if self.fast:
+            ptr, nbytes = self.engine.pressure_loop_plane_ptr(buf, first)
+            return self._view(ptr, nbytes * count, buf != self.engine.LOOP_MASK)
+        ptr, nbytes = self.engine.image_plane_ptr(E.PRESSURES_1 if buf == 0 else E.PRESSURES_2, first)
+        return self._view(ptr, nbytes * count, True)
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -155,10 +165,14 @@ class GpuSlabCompute:
 
 
 class HostSlabCompute:
-    """CPU stand-in with the same interface, for the multi-process tests: numpy arrays with ghost
-    planes, the sweep supplied by the caller (the tests pass the CPU oracle).  Not a product path."""
+    """CPU stand-in with the same interface, for the multi-process tests: numpy arrays with two ghost
+    planes per side, the sweep supplied by the caller (the tests pass the CPU oracle).  Not a product
+    path.  Loop buffers: 0..2 working pressures, 3 cell types, 4 divergence."""
 
-    def __init__(self, params: FluidParams, slab: Tuple[int, int], sweep_fn):
+    GW = 2
+    TYPES, DIV = 3, 4
+
+    def __init__(self, params: FluidParams, slab: Tuple[int, int], sweep_fn, max_sweeps: int = 2):
         import torch
 
         self.torch = torch
@@ -166,47 +180,80 @@ class HostSlabCompute:
         self.params = params
         self.z0, self.dl = slab
         self.sweep_fn = sweep_fn
-        shape = (self.dl + 2, h, w)
+        self.max_sweeps = max_sweeps
+        shape = (self.dl + 2 * self.GW, h, w)
         self.arr = {
             E.CELL_TYPES: torch.zeros(shape, dtype=torch.uint8),
             E.DIVERGENCES: torch.zeros(shape, dtype=torch.float32),
             E.PRESSURES_1: torch.zeros(shape, dtype=torch.float32),
             E.PRESSURES_2: torch.zeros(shape, dtype=torch.float32),
         }
+        self.work = [torch.zeros(shape, dtype=torch.float32) for _ in range(3)]
+        self.cur, self.prev, self.k = 0, -1, 0
+
+    def _owned(self, t):
+        return t[self.GW:self.GW + self.dl]
 
     def plane(self, image_id: int, local_z: int):
-        return self.arr[image_id][local_z + 1].view(-1)
+        return self.arr[image_id][local_z + self.GW].view(-1)
 
     def upload(self, image_id: int, array: np.ndarray):
-        self.arr[image_id][1:-1] = self.torch.from_numpy(np.ascontiguousarray(array))
+        self._owned(self.arr[image_id])[...] = self.torch.from_numpy(np.ascontiguousarray(array))
 
     def download(self, image_id: int) -> np.ndarray:
-        return self.arr[image_id][1:-1].numpy().copy()
-
-    def work_plane(self, which: int, local_z: int):
-        return self.plane(E.PRESSURES_1 if which == 0 else E.PRESSURES_2, local_z)
+        return self._owned(self.arr[image_id]).numpy().copy()
 
     def clear_pressures(self):
-        self.arr[E.PRESSURES_1][1:-1] = float(self.params.pressure_air)
-        self.arr[E.PRESSURES_2][1:-1] = float(self.params.pressure_air)
+        self._owned(self.arr[E.PRESSURES_1])[...] = float(self.params.pressure_air)
+        self._owned(self.arr[E.PRESSURES_2])[...] = float(self.params.pressure_air)
 
     def loop_begin(self):
-        pass
+        self._owned(self.work[0])[...] = self._owned(self.arr[E.PRESSURES_1])
+        self.cur, self.prev, self.k = 0, -1, 0
+        return [(self.TYPES, 2), (self.DIV, 1), (0, 2)]
 
-    def loop_end(self, iterations: int):
-        pass
+    def loop_max_sweeps(self) -> int:
+        return self.max_sweeps
 
-    def loop_sweep(self, k: int):
-        is_even_iteration = 1 if k % 2 == 0 else 0
-        src = E.PRESSURES_1 if is_even_iteration == 1 else E.PRESSURES_2
-        dst = E.PRESSURES_2 if is_even_iteration == 1 else E.PRESSURES_1
-        out = self.arr[dst].numpy()
-        ghosts = out[0].copy(), out[-1].copy()
-        # one sweep over the slab INCLUDING its ghost planes as if they were cells, then put the
-        # ghost planes of the output back: owned planes only depend on z±1, so they are exact.
+    def _other(self, a, b):
+        return next(i for i in range(3) if i not in (a, b))
+
+    def _sweep(self, src, dst):
+        # one sweep over the slab INCLUDING its ghost planes as if they were cells: with valid data g
+        # planes deep in the ghost region the result is exact g-1 planes deep (and on all owned planes)
         self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
-                      self.arr[src].numpy(), out)
-        out[0], out[-1] = ghosts
+                      self.work[src].numpy(), self.work[dst].numpy())
+
+    def loop_advance(self, k: int, sweeps: int, keep_mid: bool):
+        assert k == self.k
+        if sweeps == 2:
+            dst = self._other(self.cur, self.cur)
+            mid = self._other(self.cur, dst)
+            self._sweep(self.cur, mid)
+            self._sweep(mid, dst)
+            self.prev = mid if keep_mid else -1
+            self.cur = dst
+        else:
+            dst = self._other(self.cur, self.prev if self.prev >= 0 else self.cur)
+            self._sweep(self.cur, dst)
+            self.prev, self.cur = self.cur, dst
+        self.k += sweeps
+        return self.cur, 2
+
+    def loop_end(self):
+        if self.k == 0:
+            return
+        water = self._owned(self.arr[E.CELL_TYPES]) == int(self.params.cell_type_water)
+        even, odd = (self.cur, self.prev) if self.k % 2 == 0 else (self.prev, self.cur)
+        for img, buf in ((E.PRESSURES_1, even), (E.PRESSURES_2, odd)):
+            if buf >= 0:
+                dst = self._owned(self.arr[img])
+                dst[water] = self._owned(self.work[buf])[water]
+
+    def planes(self, buf: int, first: int, count: int):
+        t = self.work[buf] if buf < 3 else self.arr[E.CELL_TYPES if buf == self.TYPES
+                                                     else E.DIVERGENCES]
+        return t[first + self.GW:first + self.GW + count].view(-1)
 
     def sync(self):
         pass
@@ -255,23 +302,26 @@ class SlabPressureSolver:
         return self
 
     # -- halo exchange ---------------------------------------------------------------------------------
-    def _run_plan(self, key, make_plane):
-        """Send the first/last owned plane to the lower/upper neighbour, receive their last/first
-        owned plane into the ghost planes.  Grouped point-to-point, both directions at once.  The
-        tensor views and P2POps are built once per buffer and reused (the planes never move)."""
+    def _run_plan(self, key, make_planes, width: int):
+        """Send the first/last `width` owned planes to the lower/upper neighbour, receive their
+        last/first owned planes into the ghost planes.  Grouped point-to-point, both directions at
+        once.  Tensor views and P2POps are built once per buffer and reused (planes never move)."""
         import torch.distributed as dist
 
         if self.ctx.world == 1:
             return
+        if self.z_count < width:
+            raise RuntimeError(f"slab of {self.z_count} planes is thinner than the halo ({width})")
         plan = self._plans.get(key)
         if plan is None:
-            plan = []  # (is_send, plane tensor, peer)
+            plan = []  # (is_send, flat tensor of `width` planes, peer)
+            n = self.z_count
             if self.lo is not None:
-                plan.append((True, make_plane(0), self.lo))
-                plan.append((False, make_plane(-1), self.lo))
+                plan.append((True, make_planes(0, width), self.lo))
+                plan.append((False, make_planes(-width, width), self.lo))
             if self.hi is not None:
-                plan.append((True, make_plane(self.z_count - 1), self.hi))
-                plan.append((False, make_plane(self.z_count), self.hi))
+                plan.append((True, make_planes(n - width, width), self.hi))
+                plan.append((False, make_planes(n, width), self.hi))
             self._plans[key] = plan
         if self.transport == "staged":
             staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
@@ -292,31 +342,35 @@ class SlabPressureSolver:
             work.wait()
 
     def exchange(self, image_id: int):
-        """Halo exchange of an image (cell types at set-up)."""
-        self._run_plan(("img", image_id), lambda z: self.compute.plane(image_id, z))
+        """One-plane halo exchange of an image (cell types at set-up)."""
+        self._run_plan(("img", image_id), lambda z, n: self.compute.plane(image_id, z), 1)
         self.compute.halo_written(image_id)  # derived data (the neighbour mask) is rebuilt
 
-    def exchange_work(self, which: int):
-        """Halo exchange of the buffer holding the iterates of parity `which`."""
-        self._run_plan(("work", which), lambda z: self.compute.work_plane(which, z))
+    def exchange_loop_buffer(self, buf: int, width: int):
+        """Halo exchange of a buffer of the running loop, `width` planes deep."""
+        self._run_plan(("loop", buf, width), lambda z, n: self.compute.planes(buf, z, n), width)
 
     # -- the loop section ---------------------------------------------------------------------------------
     def clear_pressures(self):
         self.compute.clear_pressures()
 
     def solve(self, iterations: Optional[int] = None):
-        """FlowLoopPushConstantSection semantics: dispatch k maps iterate k (parity
-        k%2; PRESSURES_1 holds the even ones) to iterate k+1.  After every dispatch the boundary
-        planes of the buffer just written are exchanged so the next dispatch sees the neighbours'
-        new values."""
+        """FlowLoopPushConstantSection semantics: dispatch k maps iterate k to iterate
+        k+1; after N dispatches PRESSURES_1 holds the last even iterate, PRESSURES_2 the last odd one.
+        Where the engine can apply two sweeps per pass over HBM, the slabs exchange two boundary
+        planes every two sweeps instead of one plane every sweep (same bytes, half the messages)."""
         n = self.iterations if iterations is None else iterations
         c = self.compute
-        c.loop_begin()
-        self.exchange_work(0)           # iterate 0
-        for k in range(n):
-            c.loop_sweep(k)
-            self.exchange_work((k + 1) % 2)
-        c.loop_end(n)
+        for buf, width in c.loop_begin():
+            self.exchange_loop_buffer(buf, width)
+        pair = c.loop_max_sweeps() >= 2 and self.z_count >= 2
+        k = 0
+        while k < n:
+            sweeps = 2 if (pair and n - k >= 2) else 1
+            buf, width = c.loop_advance(k, sweeps, sweeps == 2 and n - k == 2)
+            self.exchange_loop_buffer(buf, min(width, self.z_count))
+            k += sweeps
+        c.loop_end()
 
     def step(self):
         self.clear_pressures()
