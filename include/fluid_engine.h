@@ -281,16 +281,25 @@ int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** de
  *             iterate
  *   end     : write the last two iterates into the water cells of PRESSURES_1 (even) / PRESSURES_2 (odd)
  * begin; advance...; end equals fluid_run_section_loop(FLUID_SEC_12_SOLVE_PRESSURE, N) for the same
- * number of sweeps.  On a Z-slab context the caller exchanges, after begin, one boundary plane of the
- * mask (buffer 3) and of b_i (buffer 4) and TWO boundary planes of working buffer 0 with each
- * neighbour, and after every advance two boundary planes of the buffer just written
- * (fluid_pressure_loop_plane_ptr: planes -2,-1 / Dl,Dl+1 are the ghost planes of buffers 0..2,
- * -1 / Dl those of buffers 3 and 4).  Needs fluid_size.x % 4 == 0, else FLUID_ERR_UNSUPPORTED (then
- * loop over fluid_run_pressure_dispatch and exchange the image planes instead). */
+ * number of sweeps.
+ * On a Z-slab context every sweep consumes one ghost plane per side of the newest iterate.  The
+ * caller exchanges boundary planes with its Z-neighbours and reports it:
+ *   after begin: h-1 planes of the mask (buffer 3) and of b_i (buffer 4) and h planes of working
+ *   buffer 0, then fluid_pressure_loop_halo_exchanged(ctx, h, h-1); 2 <= h <= FLUID_LOOP_MAX_HALO,
+ *   h <= slab_z_count.  The loop then advances h sweeps without communication (the engine computes
+ *   the shrinking ghost region redundantly), after which the caller exchanges h planes of the buffer
+ *   holding the newest iterate (*written_buffer) and calls halo_exchanged(ctx, h, 0) again.
+ *   A one-sweep advance leaves no valid ghost planes.
+ * Planes for the exchange: fluid_pressure_loop_plane_ptr (local plane numbers, -h..-1 and Dl..Dl+h-1
+ * are ghost planes; consecutive planes are contiguous in memory).
+ * Needs fluid_size.x % 4 == 0, else FLUID_ERR_UNSUPPORTED (then loop over
+ * fluid_run_pressure_dispatch and exchange one plane of the written image per sweep instead). */
+#define FLUID_LOOP_MAX_HALO 8
 int fluid_pressure_loop_begin(fluid_ctx* ctx);
 int fluid_pressure_loop_max_sweeps(fluid_ctx* ctx);
 int fluid_pressure_loop_advance(fluid_ctx* ctx, uint32_t sweeps, int keep_intermediate,
                                 int* written_buffer);
+int fluid_pressure_loop_halo_exchanged(fluid_ctx* ctx, uint32_t depth, uint32_t aux_depth);
 int fluid_pressure_loop_end(fluid_ctx* ctx);
 int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes);

@@ -38,7 +38,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, seed, max_sweeps, out_dir):
+def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -70,7 +70,7 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, out_dir):
 
     slab = partition_z(d, world)[rank]
     comp = HostSlabCompute(p, slab, sweep, max_sweeps=max_sweeps)
-    solver = SlabPressureSolver(size, iters, ctx, comp, slab)
+    solver = SlabPressureSolver(size, iters, ctx, comp, slab, halo_depth=halo)
     z0, n = slab
     comp.upload(E.CELL_TYPES, st.cell_types[z0:z0 + n])
     comp.upload(E.DIVERGENCES, st.divergences[z0:z0 + n])
@@ -89,16 +89,21 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,max_sweeps", [(2, (12, 10, 16), 6, 2), (3, (8, 9, 11), 5, 2),
-                                                         (2, (10, 8, 9), 4, 1)])
-def test_slab_solver_equals_single_domain_oracle(world, size, iters, max_sweeps, tmp_path):
+@pytest.mark.parametrize("world,size,iters,max_sweeps,halo", [
+    (2, (12, 10, 16), 6, 2, 2),    # two sweeps per exchange
+    (2, (12, 10, 16), 13, 2, 8),   # eight sweeps per exchange, odd tail
+    (3, (8, 9, 11), 5, 2, 8),      # slabs of 4/4/3 planes clip the halo to 2
+    (3, (8, 9, 20), 9, 2, 4),      # 7/7/6 planes, halo 4
+    (2, (10, 8, 9), 4, 1, 8),      # one sweep per launch: one plane per sweep
+])
+def test_slab_solver_equals_single_domain_oracle(world, size, iters, max_sweeps, halo, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal, random_state
 
     seed = 21
     port = _free_port()
-    mp.start_processes(_worker, args=(world, port, size, iters, seed, max_sweeps, str(tmp_path)),
+    mp.start_processes(_worker, args=(world, port, size, iters, seed, max_sweeps, halo, str(tmp_path)),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     st = random_state(size, seed=seed, iters=iters)

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, seed, variant, out_dir):
+def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -44,7 +44,7 @@ def _worker(rank, world, port, size, iters, seed, variant, out_dir):
     st = random_state(size, seed=seed, iters=iters)
     slab = partition_z(d, world)[rank]
     comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant)
-    solver = SlabPressureSolver(size, iters, ctx, comp, slab, transport="staged")
+    solver = SlabPressureSolver(size, iters, ctx, comp, slab, transport="staged", halo_depth=halo)
     z0, n = slab
     comp.upload(E.CELL_TYPES, st.cell_types[z0:z0 + n])
     comp.upload(E.DIVERGENCES, st.divergences[z0:z0 + n])
@@ -62,20 +62,22 @@ def _worker(rank, world, port, size, iters, seed, variant, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,variant", [
-    (2, (64, 24, 20), 6, 0),    # working-buffer loop, two sweeps per exchange
-    (3, (260, 9, 11), 5, 0),    # 3 slabs of 4/4/3 planes, odd iteration count (pair, pair, single)
-    (3, (256, 12, 13), 8, 7),   # explicit fast-path kernel option
-    (2, (64, 24, 20), 7, 2),    # general kernel on the images, one plane per sweep
-    (2, (17, 9, 8), 4, 0),      # width not a multiple of 4: falls back to the images as well
+@pytest.mark.parametrize("world,size,iters,variant,halo", [
+    (2, (64, 24, 20), 6, 0, 2),     # working-buffer loop, two sweeps per exchange
+    (2, (64, 24, 20), 21, 0, 8),    # eight sweeps per exchange (redundant ghost-region compute), odd tail
+    (2, (64, 24, 40), 12, 0, 6),    # six
+    (3, (260, 9, 11), 5, 0, 8),     # slabs of 4/4/3 planes clip the halo to 2
+    (3, (256, 12, 13), 8, 7, 4),    # explicit fast-path kernel option
+    (2, (64, 24, 20), 7, 2, 8),     # general kernel on the images: one plane per sweep
+    (2, (17, 9, 8), 4, 0, 8),       # width not a multiple of 4: falls back to the images as well
 ])
-def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, tmp_path):
+def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal, random_state
 
     seed = 33
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, seed, variant,
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, seed, variant, halo,
                                       str(tmp_path)),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))

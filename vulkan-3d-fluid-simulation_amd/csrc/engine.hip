@@ -80,10 +80,9 @@ struct fluid_ctx {
     int64_t opt[FLUID_OPT_COUNT] = {0};
 
     // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
-    uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, (Dl+2) planes each
+    uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
-    uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, (Dl+4) planes each: two ghost
-                                          // planes per side (two sweeps per halo exchange)
+    uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
     bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
     bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
@@ -92,6 +91,10 @@ struct fluid_ctx {
     int loop_cur = 0;        // working buffer of the newest iterate
     int loop_prev = -1;      // working buffer of the iterate before it, -1 = not kept
     uint32_t loop_k = 0;     // index of the newest iterate
+    int loop_halo = 0;       // Z slabs: valid ghost planes per side of work[loop_cur] (shrinks with
+                             // every sweep, restored by the caller's halo exchange)
+    int loop_aux_halo = 0;   // ... of mask / b_i (fixed for the loop)
+    bool loop_ghost_bg = false;  // ghost planes of the other two buffers hold their constants
 
     bool timing = false;
     std::vector<TimerSlot> pending;
@@ -116,10 +119,11 @@ struct fluid_ctx {
                                     (uint64_t)g.plane * img[image].elem_bytes);
     }
     float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
-    uint8_t* mask0() const { return arena + mask_offset + (uint64_t)g.plane; }
-    float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + g.plane; }
-    float* work0(int i) const {  // owned plane 0
-        return reinterpret_cast<float*>(arena + work_offset[i]) + 2 * g.plane;
+    // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
+    uint8_t* mask0() const { return arena + mask_offset + (uint64_t)LOOP_GHOST * g.plane; }
+    float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + LOOP_GHOST * g.plane; }
+    float* work0(int i) const {
+        return reinterpret_cast<float*>(arena + work_offset[i]) + LOOP_GHOST * g.plane;
     }
     uint8_t* bricks() const { return arena + active_offset; }
     // bookkeeping for the fast path: call whenever an image's device contents change
@@ -236,9 +240,9 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     L.particles_bytes = capacity * 16;
     off = align_up(off + L.particles_bytes, kAlign);
     L.mask_offset = off;
-    off = align_up(off + plane * (uint64_t)(dl + 2), kAlign);
+    off = align_up(off + plane * (uint64_t)(dl + 2 * LOOP_GHOST), kAlign);
     L.rhs_offset = off;
-    off = align_up(off + plane * (uint64_t)(dl + 2) * 4, kAlign);
+    off = align_up(off + plane * (uint64_t)(dl + 2 * LOOP_GHOST) * 4, kAlign);
     L.active_offset = off;
     {
         int nbx, nby, nbz;
@@ -248,7 +252,7 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     off = align_up(off + L.active_bytes, kAlign);
     for (int i = 0; i < 3; i++) {
         L.work_offset[i] = off;
-        off = align_up(off + plane * (uint64_t)(dl + 4) * 4, kAlign);
+        off = align_up(off + plane * (uint64_t)(dl + 2 * LOOP_GHOST) * 4, kAlign);
     }
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
@@ -444,9 +448,11 @@ int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1)
 // two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
 // j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
 int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
+    const bool lo = c->g.z0 > 0, hi = c->g.z0 + c->g.Dl < c->g.Dg;  // neighbouring slabs
     HIP_TRY(c, k12_launch_canon2(c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
                                  mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
-                                 oob_value(c)));
+                                 oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
+                                 lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -461,6 +467,9 @@ int loop_begin(fluid_ctx* c) {
     c->loop_cur = 0;
     c->loop_prev = -1;
     c->loop_k = 0;
+    c->loop_halo = 0;
+    c->loop_aux_halo = 0;
+    c->loop_ghost_bg = false;
     return rc;
 }
 // a working buffer that is neither a nor b
@@ -475,6 +484,11 @@ int other_buffer(int a, int b) {
 int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
     int rc = FLUID_OK;
     const int cur = c->loop_cur;
+    if (c->is_slab && c->loop_halo < (int)sweeps)
+        return c->fail(FLUID_ERR_INVALID_ARG,
+                       "%u sweep(s) need %u valid ghost plane(s) of the newest iterate, %d left: "
+                       "exchange halos and call fluid_pressure_loop_halo_exchanged",
+                       sweeps, sweeps, c->loop_halo);
     if (sweeps == 2) {
         const int dst = other_buffer(cur, cur);
         const int mid = keep_mid ? other_buffer(cur, dst) : -1;
@@ -484,6 +498,7 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
         c->loop_prev = mid;
         c->loop_cur = dst;
         c->loop_k += 2;
+        c->loop_halo = std::max(0, std::min(c->loop_halo - 2, c->loop_aux_halo - 1));
     } else {
         const int dst = other_buffer(cur, c->loop_prev >= 0 ? c->loop_prev : cur);
         rc = ensure_background(c, dst);
@@ -491,6 +506,7 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
         c->loop_prev = cur;
         c->loop_cur = dst;
         c->loop_k += 1;
+        c->loop_halo = 0;  // the one-sweep kernel writes owned planes only
     }
     if (written) *written = c->loop_cur;
     return rc;
@@ -1047,6 +1063,35 @@ int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermed
     return rc ? rc : rc2;
 }
 
+int fluid_pressure_loop_halo_exchanged(fluid_ctx* c, uint32_t depth, uint32_t aux_depth) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
+    if (depth > (uint32_t)LOOP_GHOST || aux_depth > (uint32_t)LOOP_GHOST)
+        return c->fail(FLUID_ERR_INVALID_ARG, "at most %d ghost planes", LOOP_GHOST);
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->loop_halo = (int)depth;
+    if (aux_depth) c->loop_aux_halo = (int)aux_depth;
+    if (!c->loop_ghost_bg && c->is_slab && depth > 0) {
+        // The sweeps store water cells only; the constants of the non-water cells in the ghost
+        // planes of the other two buffers are those just received in this buffer.
+        const uint64_t bytes = (uint64_t)depth * c->g.plane * 4;
+        const bool lo = c->g.z0 > 0, hi = c->g.z0 + c->g.Dl < c->g.Dg;
+        for (int i = 0; i < 3; i++) {
+            if (i == c->loop_cur) continue;
+            if (lo)
+                HIP_TRY(c, hipMemcpyAsync(c->work0(i) - (int64_t)depth * c->g.plane,
+                                          c->work0(c->loop_cur) - (int64_t)depth * c->g.plane, bytes,
+                                          hipMemcpyDeviceToDevice, c->stream));
+            if (hi)
+                HIP_TRY(c, hipMemcpyAsync(c->work0(i) + (int64_t)c->g.Dl * c->g.plane,
+                                          c->work0(c->loop_cur) + (int64_t)c->g.Dl * c->g.plane,
+                                          bytes, hipMemcpyDeviceToDevice, c->stream));
+        }
+        c->loop_ghost_bg = true;
+    }
+    return FLUID_OK;
+}
+
 int fluid_pressure_loop_end(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
@@ -1054,22 +1099,21 @@ int fluid_pressure_loop_end(fluid_ctx* c) {
     return loop_end(c);
 }
 
-// which: 0..2 = working pressure buffers (planes -2 .. Dl+1), 3 = mask (planes -1 .. Dl, 1 byte per
-// cell), 4 = b_i (planes -1 .. Dl)
+// which: 0..2 = working pressure buffers, 3 = mask (1 byte per cell), 4 = b_i; planes
+// -LOOP_GHOST .. Dl + LOOP_GHOST - 1
 int fluid_pressure_loop_plane_ptr(fluid_ctx* c, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
     if (which < 0 || which > 4) return c->fail(FLUID_ERR_INVALID_ARG, "loop buffer %d", which);
-    const int ghost = which <= 2 ? 2 : 1;
-    if (plane < -ghost || plane >= c->g.Dl + ghost)
-        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -ghost,
-                       c->g.Dl + ghost);
+    if (plane < -LOOP_GHOST || plane >= c->g.Dl + LOOP_GHOST)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -LOOP_GHOST,
+                       c->g.Dl + LOOP_GHOST);
     const uint64_t elem = which == 3 ? 1 : 4;
     const uint64_t pb = (uint64_t)c->g.plane * elem;
     const uint64_t base = which <= 2 ? c->work_offset[which]
                                      : (which == 3 ? c->mask_offset : c->rhs_offset);
-    *device_ptr = c->arena + base + (uint64_t)(plane + ghost) * pb;
+    *device_ptr = c->arena + base + (uint64_t)(plane + LOOP_GHOST) * pb;
     *bytes = pb;
     return FLUID_OK;
 }

@@ -21,10 +21,8 @@
 //   * rows 0 and R-1 of the group only compute iterate j+1 (halo rows); their outer y neighbour
 //     row of iterate j is loaded from global memory.
 // Works on the loop's internal working buffers (kernels_pressure.h); rows and planes outside the grid
-// are the constant p_oob for both iterates.  On a Z-slab context the working buffers carry TWO ghost
-// planes per side with the neighbouring slab's cells of iterate j (and mask / b_i one): iterate j+1 is
-// then formed on the first ghost plane as well, so the owned planes of iterate j+2 are exact and the
-// slabs exchange two planes every two sweeps.
+// are the constant p_oob for both iterates.  On a Z-slab context the working buffers carry ghost
+// planes with the neighbouring slab's cells (FusedRange below).
 #pragma once
 
 #include "pressure_common.h"
@@ -57,6 +55,17 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
     const int r = FUSED_WAVES / nt;
     return (size_t)2 /*buffers*/ * 2 /*J,S*/ * r * fused_row_floats(nt) * sizeof(float);
 }
+
+// Plane ranges of one launch (local plane indices; ghost planes are negative or >= Dl):
+//   [zout_lo, zout_hi)  planes of iterate j+2 this launch writes.  On a Z slab it may reach into the
+//                       ghost planes: with h valid ghost planes of iterate j per side a launch leaves
+//                       h-2 valid ghost planes of iterate j+2, so the slabs exchange h planes every
+//                       h sweeps instead of 2 planes every 2 (same bytes, h/2 times fewer messages)
+//   [jlo, jhi)          planes of the input buffer that hold cells of the grid
+//   [mlo, mhi)          same for mask / b_i
+struct FusedRange {
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi;
+};
 
 // Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
 // 4, so ring indices are compile-time constants and the rotation costs no register moves):
@@ -203,7 +212,8 @@ template <int NT>
 __global__ void __launch_bounds__(FUSED_THREADS)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
            const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pmid,
-           const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk) {
+           const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk,
+           FusedRange rg) {
     constexpr int R = FUSED_WAVES / NT;   // rows of iterate j+1 per workgroup
     constexpr int TY = R - 2;             // output rows per workgroup
     constexpr int RW = NT * 256 + 2 * FUSED_PAD;
@@ -218,13 +228,10 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.lds = (FLUID_LDS float*)lds;
     c.plane = g.plane;
     c.Dl = g.Dl;
-    {   // a neighbouring slab below / above: its boundary planes sit in this context's ghost planes
-        const bool lo = g.z0 > 0, hi = g.z0 + g.Dl < g.Dg;
-        c.jlo = lo ? -2 : 0;
-        c.jhi = g.Dl + (hi ? 2 : 0);
-        c.mlo = lo ? -1 : 0;
-        c.mhi = g.Dl + (hi ? 1 : 0);
-    }
+    c.jlo = rg.jlo;
+    c.jhi = rg.jhi;
+    c.mlo = rg.mlo;
+    c.mhi = rg.mhi;
     c.p_oob = p_air;
     c.lane = threadIdx.x & 63;
     // readfirstlane: tells hipcc the wave index (hence row, tile and halo role) is wave-uniform, so it
@@ -235,10 +242,12 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.x0 = tx * 256 + c.lane * 4;
     const int y0 = blockIdx.y * TY;        // first output row
     const int y = y0 - 1 + c.rr;           // this wavefront's row
-    c.zb = blockIdx.z * zchunk;
-    c.ze = min(c.zb + zchunk, g.Dl);
+    c.zb = rg.zout_lo + blockIdx.z * zchunk;
+    c.ze = min(c.zb + zchunk, rg.zout_hi);
 
-    {   // the whole group leaves if no brick it touches holds water (uniform: before any barrier)
+    if (c.zb >= 0 && c.ze <= g.Dl) {
+        // the whole group leaves if no brick it touches holds water (uniform: before any barrier);
+        // groups that write ghost planes always run (the activity map covers owned planes only)
         uint32_t any = 0;
         const int by0 = max(y0 - 1, 0) / BRICK_Y, by1 = min(y0 + TY, g.H - 1) / BRICK_Y;
         const int bz0 = max(c.zb - 1, 0) / BRICK_Z, bz1 = min(c.ze, g.Dl - 1) / BRICK_Z;

@@ -12,6 +12,10 @@ namespace fluid {
 
 struct BrickK;  // pressure_common.h
 
+// ghost planes per side of the loop's working buffers, mask and b_i (Z-slab contexts exchange up to
+// this many planes at a time and then run that many sweeps without communication)
+constexpr int LOOP_GHOST = 8;
+
 // activity-brick geometry for a grid (host arithmetic)
 void k12_brick_dims(int W, int H, int Dl, int& nbx, int& nby, int& nbz);
 
@@ -36,7 +40,7 @@ void k12_launch_canon(hipStream_t s, int rows_per_wave, const uint8_t* mask, con
 // two sweeps per pass; returns a hipError_t from the one-time LDS attribute call (hipSuccess else)
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                             float p_oob);
+                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi);
 bool k12_canon2_supports(const GridK& g);
 
 }  // namespace fluid

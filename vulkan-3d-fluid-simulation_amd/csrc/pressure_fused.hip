@@ -64,7 +64,7 @@ static int cu_count() {
 template <int NT>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                            float p_oob) {
+                            float p_oob, const FusedRange& rg) {
     static bool attr_set = false;  // per process and instantiation; the attribute is per function
     const size_t lds = fused_lds_bytes(NT);
     if (!attr_set) {
@@ -75,25 +75,35 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     }
     constexpr int TY = FUSED_WAVES / NT - 2;
     const int by = (g.H + TY - 1) / TY;
-    int zchunk = pick_zchunk(by, g.Dl, cu_count());
+    const int depth = rg.zout_hi - rg.zout_lo;
+    int zchunk = pick_zchunk(by, depth, cu_count());
     if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
-    const dim3 grid(1, by, (g.Dl + zchunk - 1) / zchunk);
+    const dim3 grid(1, by, (depth + zchunk - 1) / zchunk);
     BrickK bk;
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
     bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
     hipLaunchKernelGGL(k12_canon2<NT>, grid, dim3(FUSED_THREADS), lds, s, mask, rhs, pin, pout, pmid,
-                       bricks, bk, g, p_oob, zchunk);
+                       bricks, bk, g, p_oob, zchunk, rg);
     return hipSuccess;
 }
 
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                             float p_oob) {
+                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi) {
+    // halo_lo / halo_hi: valid ghost planes of the input below / above the owned planes (0 at a
+    // domain face); aux_*: the same for mask and b_i.  A launch consumes two planes of halo.
+    FusedRange rg;
+    rg.jlo = -halo_lo;
+    rg.jhi = g.Dl + halo_hi;
+    rg.mlo = -aux_lo;
+    rg.mhi = g.Dl + aux_hi;
+    rg.zout_lo = -std::max(0, std::min(halo_lo - 2, aux_lo - 1));
+    rg.zout_hi = g.Dl + std::max(0, std::min(halo_hi - 2, aux_hi - 1));
     const int nt = (g.W + 255) / 256;
-    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob);
-    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob);
-    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob);
+    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
+    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
+    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
     return hipErrorInvalidValue;
 }
 

@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
-    "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
+    "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_get_geometry", "fluid_set_option",
 ]
 
@@ -135,6 +135,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
         "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
+        "fluid_pressure_loop_halo_exchanged": (C.c_int, [vp, u32, u32]),
         "fluid_pressure_loop_end": (C.c_int, [vp]),
         "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
                                                     C.POINTER(u64)]),
@@ -341,6 +342,7 @@ class FluidEngine:
     # -- multi-GPU plumbing ---------------------------------------------------------------------------
     # the loop section in explicit form (fluid_pressure_loop_*)
     LOOP_MASK, LOOP_RHS = 3, 4  # buffer ids of fluid_pressure_loop_plane_ptr besides 0..2
+    LOOP_MAX_HALO = 8           # FLUID_LOOP_MAX_HALO
 
     def pressure_loop_begin(self):
         self._check(self._lib.fluid_pressure_loop_begin(self._h))
@@ -357,6 +359,9 @@ class FluidEngine:
                                                           1 if keep_intermediate else 0,
                                                           C.byref(written)))
         return int(written.value)
+
+    def pressure_loop_halo_exchanged(self, depth: int, aux_depth: int = 0):
+        self._check(self._lib.fluid_pressure_loop_halo_exchanged(self._h, depth, aux_depth))
 
     def pressure_loop_end(self):
         self._check(self._lib.fluid_pressure_loop_end(self._h))

@@ -125,23 +125,33 @@ class GpuSlabCompute:
     # ---- the loop section in explicit form (include/fluid_engine.h: fluid_pressure_loop_*) ----
     # A "loop buffer" is anything the slabs must exchange boundary planes of.  planes(buf, first, n)
     # returns n consecutive local planes starting at `first` as one flat tensor (contiguous memory).
-    def loop_begin(self):
-        """Returns [(buffer, ghost_width)] to exchange once, before the first advance."""
+    def max_halo(self) -> int:
+        """Deepest halo this backend can use (planes per exchange = sweeps between exchanges)."""
+        return self.engine.LOOP_MAX_HALO if self.fast else 1
+
+    def loop_begin(self, halo: int):
+        """Returns [(buffer, planes)] to exchange once before the first advance; the newest
+        iterate is then in buffer 0 with `halo` valid ghost planes (after loop_halo_exchanged)."""
         if self.fast:
             self.engine.pressure_loop_begin()
-            return [(self.engine.LOOP_MASK, 1), (self.engine.LOOP_RHS, 1), (0, 2)]
+            aux = max(halo - 1, 1)
+            return [(self.engine.LOOP_MASK, aux), (self.engine.LOOP_RHS, aux), (0, halo)]
         return [(0, 1), (1, 1)]  # the two pressure images themselves
+
+    def loop_halo_exchanged(self, halo: int, first: bool):
+        if self.fast:
+            self.engine.pressure_loop_halo_exchanged(halo, max(halo - 1, 1) if first else 0)
 
     def loop_max_sweeps(self) -> int:
         return self.engine.pressure_loop_max_sweeps() if self.fast else 1
 
-    def loop_advance(self, k: int, sweeps: int, keep_mid: bool):
-        """Sweeps k .. k+sweeps-1.  Returns (buffer written, ghost width to exchange)."""
+    def loop_advance(self, k: int, sweeps: int, keep_mid: bool) -> int:
+        """Sweeps k .. k+sweeps-1.  Returns the buffer that now holds the newest iterate."""
         if self.fast:
-            return self.engine.pressure_loop_advance(sweeps, keep_mid), 2
+            return self.engine.pressure_loop_advance(sweeps, keep_mid)
         assert sweeps == 1
         self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
-        return (k + 1) % 2, 1
+        return (k + 1) % 2
 
     def loop_end(self):
         if self.fast:
@@ -165,11 +175,11 @@ class GpuSlabCompute:
 
 
 class HostSlabCompute:
-    """CPU stand-in with the same interface, for the multi-process tests: numpy arrays with two ghost
+    """CPU stand-in with the same interface, for the multi-process tests: numpy arrays with GW ghost
     planes per side, the sweep supplied by the caller (the tests pass the CPU oracle).  Not a product
     path.  Loop buffers: 0..2 working pressures, 3 cell types, 4 divergence."""
 
-    GW = 2
+    GW = 8
     TYPES, DIV = 3, 4
 
     def __init__(self, params: FluidParams, slab: Tuple[int, int], sweep_fn, max_sweeps: int = 2):
@@ -207,10 +217,16 @@ class HostSlabCompute:
         self._owned(self.arr[E.PRESSURES_1])[...] = float(self.params.pressure_air)
         self._owned(self.arr[E.PRESSURES_2])[...] = float(self.params.pressure_air)
 
-    def loop_begin(self):
+    def max_halo(self) -> int:
+        return self.GW
+
+    def loop_begin(self, halo: int):
         self._owned(self.work[0])[...] = self._owned(self.arr[E.PRESSURES_1])
         self.cur, self.prev, self.k = 0, -1, 0
-        return [(self.TYPES, 2), (self.DIV, 1), (0, 2)]
+        return [(self.TYPES, halo), (self.DIV, max(halo - 1, 1)), (0, halo)]
+
+    def loop_halo_exchanged(self, halo: int, first: bool):
+        pass
 
     def loop_max_sweeps(self) -> int:
         return self.max_sweeps
@@ -238,7 +254,7 @@ class HostSlabCompute:
             self._sweep(self.cur, dst)
             self.prev, self.cur = self.cur, dst
         self.k += sweeps
-        return self.cur, 2
+        return self.cur
 
     def loop_end(self):
         if self.k == 0:
@@ -268,7 +284,12 @@ class HostSlabCompute:
 # ---- the solver ------------------------------------------------------------------------------------------
 class SlabPressureSolver:
     def __init__(self, size, iterations: int, ctx: DistContext, compute, slab: Tuple[int, int],
-                 transport: str = "direct"):
+                 transport: str = "direct", halo_depth: int = 8):
+        # halo_depth h: the slabs exchange h boundary planes at a time and then run h sweeps without
+        # communication, recomputing the shrinking ghost region (same bytes on the wire as one plane
+        # per sweep, h times fewer messages and host round trips).  Clipped to what the compute
+        # backend and the slab thickness allow; even, so sweeps can go in pairs.
+        self.halo_depth = halo_depth
         # transport "direct": the communicator addresses the planes where they live (RCCL on
         # device memory, gloo on host memory).  "staged": bounce through host tensors — only for
         # rehearsing the GPU slab path over gloo on a box with a single GPU (tests).
@@ -282,6 +303,7 @@ class SlabPressureSolver:
         self.hi = ctx.rank + 1 if ctx.rank < ctx.world - 1 else None
         self._plans = {}
         self._ops = {}
+        self.exchanges = 0  # halo exchanges performed (diagnostics)
 
     @classmethod
     def create_gpu(cls, size, iterations: int, ctx: DistContext, pressure_kernel: int = 0,
@@ -310,6 +332,7 @@ class SlabPressureSolver:
 
         if self.ctx.world == 1:
             return
+        self.exchanges += 1
         if self.z_count < width:
             raise RuntimeError(f"slab of {self.z_count} planes is thinner than the halo ({width})")
         plan = self._plans.get(key)
@@ -354,21 +377,38 @@ class SlabPressureSolver:
     def clear_pressures(self):
         self.compute.clear_pressures()
 
+    def effective_halo(self) -> int:
+        # every rank must come to the same depth: limit by the thinnest slab of the partition
+        thinnest = min(n for _, n in partition_z(self.size[2], self.ctx.world))
+        h = min(self.halo_depth, self.compute.max_halo(), thinnest)
+        if self.compute.loop_max_sweeps() >= 2 and h >= 2:
+            h -= h % 2
+        return max(h, 1)
+
     def solve(self, iterations: Optional[int] = None):
         """FlowLoopPushConstantSection semantics: dispatch k maps iterate k to iterate
         k+1; after N dispatches PRESSURES_1 holds the last even iterate, PRESSURES_2 the last odd one.
-        Where the engine can apply two sweeps per pass over HBM, the slabs exchange two boundary
-        planes every two sweeps instead of one plane every sweep (same bytes, half the messages)."""
+        Every sweep consumes one valid ghost plane per side; when fewer are left than the next
+        launch needs (2 for a two-sweeps-per-pass launch), `h` boundary planes of the newest iterate
+        are exchanged with the two Z-neighbours."""
         n = self.iterations if iterations is None else iterations
         c = self.compute
-        for buf, width in c.loop_begin():
+        h = self.effective_halo()
+        for buf, width in c.loop_begin(h):
             self.exchange_loop_buffer(buf, width)
-        pair = c.loop_max_sweeps() >= 2 and self.z_count >= 2
+        c.loop_halo_exchanged(h, True)
+        valid = h          # valid ghost planes of the newest iterate
+        cur = 0            # buffer holding it
+        pair = c.loop_max_sweeps() >= 2 and h >= 2
         k = 0
         while k < n:
             sweeps = 2 if (pair and n - k >= 2) else 1
-            buf, width = c.loop_advance(k, sweeps, sweeps == 2 and n - k == 2)
-            self.exchange_loop_buffer(buf, min(width, self.z_count))
+            if valid < sweeps:
+                self.exchange_loop_buffer(cur, h)
+                c.loop_halo_exchanged(h, False)
+                valid = h
+            cur = c.loop_advance(k, sweeps, sweeps == 2 and n - k == 2)
+            valid = valid - 2 if sweeps == 2 else 0
             k += sweeps
         c.loop_end()
 
