@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <tuple>
 #include <vector>
 
 namespace fluid {
@@ -16,8 +18,11 @@ bool k12_canon2_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 1024 &&
 // pipeline steps + a fixed start-up) to the CUs in launch order, and take the best.  Host
 // arithmetic, cached per geometry.
 static int pick_zchunk(int row_groups, int depth, int cus) {
-    static int c_groups = -1, c_depth = -1, c_cus = -1, c_result = 0;
-    if (row_groups == c_groups && depth == c_depth && cus == c_cus) return c_result;
+    // cached per geometry (a slab loop alternates between a few depths; the model costs ~1 ms)
+    static std::map<std::tuple<int, int, int>, int> cache;
+    const auto key = std::make_tuple(row_groups, depth, cus);
+    const auto hit = cache.find(key);
+    if (hit != cache.end()) return hit->second;
     const double startup = 3.0;
     double best_cost = 1e300;
     int best = std::min(depth, 32);
@@ -42,10 +47,7 @@ static int pick_zchunk(int row_groups, int depth, int cus) {
             best = zc;
         }
     }
-    c_groups = row_groups;
-    c_depth = depth;
-    c_cus = cus;
-    c_result = best;
+    cache[key] = best;
     return best;
 }
 

@@ -330,7 +330,7 @@ class SlabPressureSolver:
         once.  Tensor views and P2POps are built once per buffer and reused (planes never move)."""
         import torch.distributed as dist
 
-        if self.ctx.world == 1:
+        if self.ctx.world == 1 and self.transport != "loopback":
             return
         self.exchanges += 1
         if self.z_count < width:
@@ -346,6 +346,14 @@ class SlabPressureSolver:
                 plan.append((True, make_planes(n - width, width), self.hi))
                 plan.append((False, make_planes(n, width), self.hi))
             self._plans[key] = plan
+        if self.transport == "loopback":
+            # single-process rehearsal of one rank's work (tools/slab_rank_sim.py): every receive is
+            # filled by a device copy of a send buffer of the same size; no communicator involved
+            sends = [t for snd, t, _ in plan if snd]
+            recvs = [t for snd, t, _ in plan if not snd]
+            for i, r in enumerate(recvs):
+                r.copy_(sends[(i + 1) % len(sends)])
+            return
         if self.transport == "staged":
             staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
                       for snd, t, peer in plan]
