@@ -268,8 +268,9 @@ int fluid_reset_timing(fluid_ctx* ctx);
 
 /* ---- multi-GPU plumbing (Z-slab contexts) ------------------------------------------------------
  * Device address and byte count of one XY plane of an image, for halo exchange by the caller's
- * communicator (RCCL Send/Recv).  `plane` is a LOCAL z index: -1 = lower ghost plane,
- * 0 … z_count-1 = owned planes, z_count = upper ghost plane.  Planes are contiguous in memory.    */
+ * communicator (RCCL Send/Recv).  `plane` is a LOCAL z index: 0 … z_count-1 = owned planes,
+ * -FLUID_IMAGE_GHOST_PLANES … -1 and z_count … z_count+FLUID_IMAGE_GHOST_PLANES-1 = ghost planes.
+ * Consecutive planes are contiguous in memory.                                                   */
 int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** device_ptr,
                           uint64_t* bytes);
 /* The loop section in explicit form, for callers that must act between launches (halo exchange):
@@ -308,6 +309,29 @@ int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void
  * from fluid_image_plane_ptr (halo exchange), so data the engine derives from it is rebuilt.
  * Ghost planes of PRESSURES_1/2 must carry the neighbouring slab's cells of the same buffer. */
 int fluid_notify_image_written(fluid_ctx* ctx, int image_id);
+/* Z-slab contexts, full step.  The caller runs the sections one by one (fluid_run_section) and
+ * exchanges ghost planes between them (fluid_image_plane_ptr, FLUID_IMAGE_GHOST_PLANES per side):
+ *   after 02 and after 03: NEW_CELL_TYPES, 1 plane          (03 / 05 read z-1, z+1)
+ *   after 05: VELOCITIES_1, FLUID_IMAGE_GHOST_PLANES planes (07 samples it; 04 of the next step reads z+-1)
+ *   after 10: VELOCITIES_1, 1 plane                         (11 reads z+1)
+ *   after the pressure loop: PRESSURES_2, 1 plane           (13 reads z-1)
+ *   after 13: VELOCITIES_1, FLUID_IMAGE_GHOST_PLANES planes (14 samples it)
+ *   after 14: particle migration (below)
+ * 06 copies one ghost plane per side along with the owned planes.  The velocity sampler of 07 / 14
+ * can reach as far as the fluid moves in one step; a tap beyond the ghost planes raises the halo
+ * violation flag (fluid_slab_status reads and clears it): results of that step are then not exact.
+ *
+ * Particles: every rank holds the full-capacity buffer; global particle i lives in slot i of the rank
+ * whose slab contains the plane the particle counts towards (01_update_densities), the other ranks
+ * hold a tombstone there (w = bit pattern 0x7FC0DEAD).  fluid_upload_buffer(PARTICLES_BUF) takes the
+ * global array and keeps the owned slots.  After 14: collect_leavers lists (device memory, 32-byte
+ * entries {float4 data; uint32 index; 3 x pad}) the particles that left this slab and buries them; the
+ * caller all-gathers the lists and every rank adopts the entries that are now its own. */
+#define FLUID_IMAGE_GHOST_PLANES 4
+int fluid_slab_status(fluid_ctx* ctx, uint32_t* halo_violation);
+int fluid_particles_collect_leavers(fluid_ctx* ctx, void** device_list, uint32_t* count);
+int fluid_particles_adopt(fluid_ctx* ctx, const void* device_list, uint32_t count);
+
 /* Geometry of this context. */
 int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* slab_z_begin,
                        uint32_t* slab_z_count, uint64_t* particle_capacity);

@@ -1,9 +1,9 @@
 // device_common.h — shared device-side definitions for the gfx950 fluid-step kernels.
 //
 // Memory model of one context (one GPU, one Z-slab of the global grid):
-//   every grid image holds (Dl + 2) XY planes, x fastest: one ghost plane below local z = -1, the Dl
-//   owned planes, one ghost plane above.  Kernel pointers address owned plane 0, so local z in
-//   [-1, Dl] is always a valid load.  Ghost planes at a domain face stay zero for the lifetime of
+//   every grid image holds Dl + 2*IMG_GHOST XY planes, x fastest: IMG_GHOST ghost planes below the Dl
+//   owned planes and as many above.  Kernel pointers address owned plane 0, so local z in
+//   [-IMG_GHOST, Dl + IMG_GHOST) is always a valid load.  Ghost planes at a domain face stay zero for the lifetime of
 //   the context, which IS the reference's out-of-bounds image semantics in z ("load returns 0",
 //   SURVEY.md F4); ghost planes between two slabs are filled by the caller's halo exchange.
 //   x and y out-of-bounds are tested in the kernels.
@@ -17,6 +17,16 @@
 #include <stdint.h>
 
 namespace fluid {
+
+// Ghost planes per side of every grid image.  The stencil passes read one; the velocity sampler of
+// 07_advect / 14_particles may reach further (a backtrace or a particle can cross a slab face), up
+// to this many planes, beyond which the context raises its halo-violation flag.
+constexpr int IMG_GHOST = 4;
+
+// Particle slots a Z-slab context does not own carry this bit pattern in w (a quiet NaN, so it is
+// never equal to active_particle_w): "tombstones".  Global particle i lives, with its real data, in
+// slot i of exactly one rank — the one whose slab holds the cell the particle counts towards.
+constexpr uint32_t PARTICLE_TOMBSTONE_BITS = 0x7FC0DEADu;
 
 struct GridK {
     int W, H, Dl;   // local extents (Dl = owned planes)
@@ -41,6 +51,14 @@ struct ParamsK {
     float fountain_force;                          // 252
     float repel;                                   // 256
 };
+
+// Global z plane a particle belongs to: the plane 01_update_densities counts it in (ivec3()
+// truncation, update_densities.comp:35), clamped into the grid so every particle has an owner.
+__device__ __forceinline__ int particle_owner_plane(float z, int Dg) {
+    if (!(z > 0.0f)) return 0;            // also NaN and everything that truncates to <= 0
+    if (z >= (float)Dg) return Dg - 1;
+    return (int)z;
+}
 
 __device__ __forceinline__ int64_t cidx(const GridK& g, int x, int y, int lz) {
     return (int64_t)x + (int64_t)g.W * ((int64_t)y + (int64_t)g.H * (int64_t)lz);

@@ -47,8 +47,8 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 struct ImageDesc {
     uint32_t elem_bytes = 0;   // bytes per cell
-    uint64_t offset = 0;       // arena offset of ghost plane -1
-    uint64_t bytes = 0;        // (Dl + 2) planes
+    uint64_t offset = 0;       // arena offset of ghost plane -IMG_GHOST
+    uint64_t bytes = 0;        // Dl + 2*IMG_GHOST planes
 };
 
 struct TimerSlot {
@@ -83,6 +83,9 @@ struct fluid_ctx {
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
+    uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter
+    uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
+    uint32_t leavers_capacity = 0;
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
     bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
     bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
@@ -114,9 +117,9 @@ struct fluid_ctx {
         return code;
     }
     template <typename T>
-    T* plane0(int image) const {  // owned plane 0
+    T* plane0(int image) const {  // owned plane 0 (IMG_GHOST ghost planes in front of it)
         return reinterpret_cast<T*>(arena + img[image].offset +
-                                    (uint64_t)g.plane * img[image].elem_bytes);
+                                    (uint64_t)IMG_GHOST * g.plane * img[image].elem_bytes);
     }
     float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
     // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
@@ -126,6 +129,8 @@ struct fluid_ctx {
         return reinterpret_cast<float*>(arena + work_offset[i]) + LOOP_GHOST * g.plane;
     }
     uint8_t* bricks() const { return arena + active_offset; }
+    uint32_t* flags() const { return reinterpret_cast<uint32_t*>(arena + flags_offset); }
+    Leaver* leavers() const { return reinterpret_cast<Leaver*>(arena + leavers_offset); }
     // bookkeeping for the fast path: call whenever an image's device contents change
     void touched(int image) {
         if (image == FLUID_IMG_CELL_TYPES) {
@@ -214,6 +219,8 @@ struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
     uint64_t mask_offset, rhs_offset, active_offset, active_bytes, work_offset[3];
+    uint64_t flags_offset, leavers_offset;
+    uint32_t leavers_capacity;
     uint64_t total;
 };
 
@@ -233,7 +240,7 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     uint64_t off = 0;
     for (int i = 0; i < 8; i++) {
         L.img_offset[i] = off;
-        L.img_bytes[i] = plane * (uint64_t)(dl + 2) * kElemBytes[i];
+        L.img_bytes[i] = plane * (uint64_t)(dl + 2 * IMG_GHOST) * kElemBytes[i];
         off = align_up(off + L.img_bytes[i], kAlign);
     }
     L.particles_offset = off;
@@ -254,6 +261,15 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
         L.work_offset[i] = off;
         off = align_up(off + plane * (uint64_t)(dl + 2 * LOOP_GHOST) * 4, kAlign);
     }
+    L.flags_offset = off;
+    off = align_up(off + 256, kAlign);
+    // room for every particle to leave in one step is never needed; a quarter of them (at least 64 Ki
+    // entries) is generous, and an overflow is reported, not ignored
+    const bool slab = dl != p.fluid_size[2];
+    L.leavers_capacity =
+        slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(capacity / 4, 65536), 0x7FFFFFFFu) : 0;
+    L.leavers_offset = off;
+    off = align_up(off + (uint64_t)L.leavers_capacity * sizeof(Leaver), kAlign);
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
 }
@@ -568,7 +584,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_00_INIT_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
             hipLaunchKernelGGL(k00_init_particles, dim3(pblocks), dim3(256), 0, c->stream,
-                               c->particles(), c->particle_capacity, pk);
+                               c->particles(), c->particle_capacity, pk, g, c->is_slab ? 1 : 0);
             break;
         case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES:
             return fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
@@ -595,17 +611,20 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
-            HIP_TRY(c, hipMemcpyAsync(T, newT, c->owned_cells(), hipMemcpyDeviceToDevice,
-                                      c->stream));
+            // one ghost plane per side rides along: on a slab it holds the neighbour's new types
+            // (exchanged after 03), at a domain face it is zero in both images
+            HIP_TRY(c, hipMemcpyAsync(T - g.plane, newT - g.plane, c->owned_cells() + 2 * g.plane,
+                                      hipMemcpyDeviceToDevice, c->stream));
             return FLUID_OK;
         case FLUID_SEC_07_ADVECT:
-            if (c->is_slab) return slab_unsupported(c, "07_advect");
-            hipLaunchKernelGGL(k07_advect, grid, block, 0, c->stream, T, V1, V2, g, pk);
+            hipLaunchKernelGGL(k07_advect, grid, block, 0, c->stream, T, V1, V2, g, pk, c->flags());
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
             break;
         case FLUID_SEC_09_DIFFUSE:
+            if (c->diffuse_mode == FLUID_DIFFUSE_INTENDED && c->is_slab)
+                return slab_unsupported(c, "09_diffuse in FLUID_DIFFUSE_INTENDED mode");
             if (c->diffuse_mode == FLUID_DIFFUSE_INTENDED)
                 hipLaunchKernelGGL(k09_diffuse<true>, grid, block, 0, c->stream, T, V2, V1, g, pk);
             else
@@ -635,10 +654,9 @@ int run_section_impl(fluid_ctx* c, int section) {
                                c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk);
             break;
         case FLUID_SEC_14_PARTICLES:
-            if (c->is_slab) return slab_unsupported(c, "14_particles");
             if (c->particle_capacity == 0) return FLUID_OK;
             hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
-                               c->particles(), c->particle_capacity, g, pk);
+                               c->particles(), c->particle_capacity, g, pk, c->flags());
             break;
         default:
             return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section);
@@ -811,6 +829,9 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->active_offset = L.active_offset;
     c->active_bytes = L.active_bytes;
     for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
+    c->flags_offset = L.flags_offset;
+    c->leavers_offset = L.leavers_offset;
+    c->leavers_capacity = L.leavers_capacity;
     c->arena_bytes = L.total;
 
     auto bail = [&](int code, const std::string& msg) {
@@ -953,6 +974,11 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
     HIP_TRY(c, hipSetDevice(c->device));
     if (bytes) {
         HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
+        if (c->is_slab) {  // the caller passes the global array: keep what this slab owns
+            const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
+            hipLaunchKernelGGL(k_particles_filter, dim3(blocks), dim3(256), 0, c->stream,
+                               c->particles(), c->particle_capacity, c->g);
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return FLUID_OK;
@@ -1220,10 +1246,11 @@ int fluid_image_plane_ptr(fluid_ctx* c, int image_id, int32_t plane, void** devi
     if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
     int rc = check_image(c, image_id);
     if (rc) return rc;
-    if (plane < -1 || plane > c->g.Dl)
-        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [-1, %d]", plane, c->g.Dl);
+    if (plane < -IMG_GHOST || plane >= c->g.Dl + IMG_GHOST)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -IMG_GHOST,
+                       c->g.Dl + IMG_GHOST);
     const uint64_t pb = (uint64_t)c->g.plane * c->img[image_id].elem_bytes;
-    *device_ptr = c->arena + c->img[image_id].offset + (uint64_t)(plane + 1) * pb;
+    *device_ptr = c->arena + c->img[image_id].offset + (uint64_t)(plane + IMG_GHOST) * pb;
     *bytes = pb;
     return FLUID_OK;
 }
@@ -1233,6 +1260,55 @@ int fluid_notify_image_written(fluid_ctx* c, int image_id) {
     int rc = check_image(c, image_id);
     if (rc) return rc;
     c->touched(image_id);  // derived data (neighbour mask, b_i, working-buffer constants) is rebuilt
+    return FLUID_OK;
+}
+
+int fluid_slab_status(fluid_ctx* c, uint32_t* halo_violation) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!halo_violation) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t v = 0;
+    HIP_TRY(c, hipMemcpyAsync(&v, c->flags(), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *halo_violation = v;
+    if (v) HIP_TRY(c, hipMemsetAsync(c->flags(), 0, 4, c->stream));
+    return FLUID_OK;
+}
+
+int fluid_particles_collect_leavers(fluid_ctx* c, void** device_list, uint32_t* count) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!device_list || !count) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    *device_list = c->leavers();
+    *count = 0;
+    if (!c->is_slab || c->particle_capacity == 0) return FLUID_OK;
+    uint32_t* counter = c->flags() + 1;
+    HIP_TRY(c, hipMemsetAsync(counter, 0, 4, c->stream));
+    const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
+    hipLaunchKernelGGL(k_particles_collect_leavers, dim3(blocks), dim3(256), 0, c->stream,
+                       c->particles(), c->particle_capacity, c->g, c->leavers(), counter,
+                       c->leavers_capacity);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n > c->leavers_capacity)
+        return c->fail(FLUID_ERR_OUT_OF_MEMORY,
+                       "%u particles left the slab in one step, the migration list holds %u", n,
+                       c->leavers_capacity);
+    *count = n;
+    return FLUID_OK;
+}
+
+int fluid_particles_adopt(fluid_ctx* c, const void* device_list, uint32_t count) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (count == 0) return FLUID_OK;
+    if (!device_list) return c->fail(FLUID_ERR_INVALID_ARG, "null leaver list");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_particles_adopt, dim3((count + 255) / 256), dim3(256), 0, c->stream,
+                       c->particles(), c->particle_capacity, c->g,
+                       static_cast<const Leaver*>(device_list), count);
+    HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
 

@@ -34,7 +34,7 @@ __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f
 // have z0 = 0).  The eight taps are scalar loads of one channel of the texel.
 template <int COMP>
 __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const GridK& g, float px,
-                                             float py, float pz) {
+                                             float py, float pz, uint32_t* __restrict__ violation) {
     const float mx = COMP == 0 ? 0.5f : 0.0f, my = COMP == 1 ? 0.5f : 0.0f,
                 mz = COMP == 2 ? 0.5f : 0.0f;
     int x0, x1, y0, y1, z0, z1;
@@ -44,6 +44,15 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
     axis_taps(pz + mz, g.Dg, z0, z1, az);
     z0 -= g.z0;
     z1 -= g.z0;
+    {   // Z-slab contexts hold IMG_GHOST planes of the neighbouring slabs: a tap beyond them cannot be
+        // served (never happens on a whole-grid context, whose taps are clamped into the grid above)
+        const int lo = -IMG_GHOST, hi = g.Dl + IMG_GHOST - 1;
+        if (z0 < lo || z1 > hi) {
+            *violation = 1u;
+            z0 = min(max(z0, lo), hi);
+            z1 = min(max(z1, lo), hi);
+        }
+    }
     const float* __restrict__ f = reinterpret_cast<const float*>(v) + COMP;
     const float c000 = f[4 * cidx(g, x0, y0, z0)], c100 = f[4 * cidx(g, x1, y0, z0)];
     const float c010 = f[4 * cidx(g, x0, y1, z0)], c110 = f[4 * cidx(g, x1, y1, z0)];
@@ -59,7 +68,8 @@ template <int COMP>
 __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
                                                   const float4* __restrict__ v1, const GridK& g,
                                                   const ParamsK& p, int x, int y, int lz, int gz,
-                                                  bool cur_water, float keep) {
+                                                  bool cur_water, float keep,
+                                                  uint32_t* __restrict__ violation) {
     const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
     // advect.comp:65-68: move[c] = -1; cellAt(pos - move) is the cell at pos + e_c
     const uint32_t nt =
@@ -68,17 +78,19 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
         const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
         const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
         const float qz = (float)gz + (COMP == 2 ? 0.0f : 0.5f);
-        const float vx = sample_comp<0>(v1, g, qx, qy, qz);  // :75
-        const float vy = sample_comp<1>(v1, g, qx, qy, qz);
-        const float vz = sample_comp<2>(v1, g, qx, qy, qz);
-        return sample_comp<COMP>(v1, g, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt);  // :77
+        const float vx = sample_comp<0>(v1, g, qx, qy, qz, violation);  // :75
+        const float vy = sample_comp<1>(v1, g, qx, qy, qz, violation);
+        const float vz = sample_comp<2>(v1, g, qx, qy, qz, violation);
+        return sample_comp<COMP>(v1, g, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
+                                 violation);  // :77
     }
     return keep;  // :79
 }
 
 // 07_advect/advect.comp:84-97
 __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
-                           float4* __restrict__ v2, GridK g, ParamsK p) {
+                           float4* __restrict__ v2, GridK g, ParamsK p,
+                           uint32_t* __restrict__ violation) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lz = blockIdx.z;
@@ -88,23 +100,24 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
     const float4 cur = v1[id];                          // :87
     const bool cur_water = (uint32_t)t[id] == p.t_water;  // :93
     float4 o;
-    o.x = advect_component<0>(t, v1, g, p, x, y, lz, gz, cur_water, cur.x);
-    o.y = advect_component<1>(t, v1, g, p, x, y, lz, gz, cur_water, cur.y);
-    o.z = advect_component<2>(t, v1, g, p, x, y, lz, gz, cur_water, cur.z);
+    o.x = advect_component<0>(t, v1, g, p, x, y, lz, gz, cur_water, cur.x, violation);
+    o.y = advect_component<1>(t, v1, g, p, x, y, lz, gz, cur_water, cur.y, violation);
+    o.z = advect_component<2>(t, v1, g, p, x, y, lz, gz, cur_water, cur.z, violation);
     o.w = 0.0f;
     v2[id] = o;  // :96
 }
 
 // 14_particles/particles.comp:45-51
 __global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict__ particles,
-                              uint64_t capacity, GridK g, ParamsK p) {
+                              uint64_t capacity, GridK g, ParamsK p,
+                              uint32_t* __restrict__ violation) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
     float4 q = particles[i];
     if (q.w == p.active_w) {  // :48
-        const float vx = sample_comp<0>(v1, g, q.x, q.y, q.z);
-        const float vy = sample_comp<1>(v1, g, q.x, q.y, q.z);
-        const float vz = sample_comp<2>(v1, g, q.x, q.y, q.z);
+        const float vx = sample_comp<0>(v1, g, q.x, q.y, q.z, violation);
+        const float vy = sample_comp<1>(v1, g, q.x, q.y, q.z, violation);
+        const float vz = sample_comp<2>(v1, g, q.x, q.y, q.z, violation);
         q.x = q.x + vx * p.dt;  // :50
         q.y = q.y + vy * p.dt;
         q.z = q.z + vz * p.dt;
@@ -112,8 +125,57 @@ __global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict_
     }
 }
 
+// ---- particle ownership on Z-slab contexts ------------------------------------------------------
+__device__ __forceinline__ bool is_tombstone(const float4& q) {
+    return __float_as_uint(q.w) == PARTICLE_TOMBSTONE_BITS;
+}
+__device__ __forceinline__ bool slab_owns(const GridK& g, float z) {
+    const int pl = particle_owner_plane(z, g.Dg) - g.z0;
+    return (unsigned)pl < (unsigned)g.Dl;
+}
+__device__ __forceinline__ float4 tombstone() {
+    return make_float4(0.f, 0.f, 0.f, __uint_as_float(PARTICLE_TOMBSTONE_BITS));
+}
+// after an upload of the global particle array: keep the slots this slab owns, bury the rest
+__global__ void k_particles_filter(float4* __restrict__ particles, uint64_t capacity, GridK g) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    if (!slab_owns(g, particles[i].z)) particles[i] = tombstone();
+}
+// A "leaver": a particle this slab holds but no longer owns (14_particles moved it across a face).
+struct Leaver {
+    float4 data;
+    uint32_t index, pad0, pad1, pad2;
+};
+__global__ void k_particles_collect_leavers(float4* __restrict__ particles, uint64_t capacity,
+                                            GridK g, Leaver* __restrict__ list,
+                                            uint32_t* __restrict__ counter, uint32_t list_capacity) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    const float4 q = particles[i];
+    if (is_tombstone(q) || slab_owns(g, q.z)) return;
+    const uint32_t slot = atomicAdd(counter, 1u);
+    if (slot < list_capacity) {  // else: counter > capacity tells the host to retry with more room
+        Leaver l;
+        l.data = q;
+        l.index = (uint32_t)i;
+        l.pad0 = l.pad1 = l.pad2 = 0u;
+        list[slot] = l;
+        particles[i] = tombstone();
+    }
+}
+// adopt the leavers of all ranks that now belong to this slab
+__global__ void k_particles_adopt(float4* __restrict__ particles, uint64_t capacity, GridK g,
+                                  const Leaver* __restrict__ list, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Leaver l = list[i];
+    if (l.index < capacity && slab_owns(g, l.data.z)) particles[l.index] = l.data;
+}
+
 // 00_init_particles/init_particles.comp:27-50
-__global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capacity, ParamsK p) {
+__global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capacity, ParamsK p,
+                                   GridK g, int slab) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // :48
@@ -130,6 +192,7 @@ __global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capa
         o.z = p.spawn_offset[2] + ((1.0f * (float)cz) / (float)p.spawn_res[2]) * p.spawn_size[2];
         o.w = p.active_w;  // :45
     }
+    if (slab && !slab_owns(g, o.z)) o = tombstone();
     particles[i] = o;
 }
 

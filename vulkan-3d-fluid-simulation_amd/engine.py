@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = [
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
+    "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
     "fluid_get_geometry", "fluid_set_option",
 ]
 
@@ -139,6 +140,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_end": (C.c_int, [vp]),
         "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
                                                     C.POINTER(u64)]),
+        "fluid_slab_status": (C.c_int, [vp, C.POINTER(u32)]),
+        "fluid_particles_collect_leavers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(u32)]),
+        "fluid_particles_adopt": (C.c_int, [vp, vp, u32]),
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
@@ -371,6 +375,25 @@ class FluidEngine:
         self._check(self._lib.fluid_pressure_loop_plane_ptr(self._h, which, plane, C.byref(ptr),
                                                             C.byref(nbytes)))
         return int(ptr.value), int(nbytes.value)
+
+    # Z-slab full step (include/fluid_engine.h)
+    IMAGE_GHOST_PLANES = 4      # FLUID_IMAGE_GHOST_PLANES
+    LEAVER_BYTES = 32           # {float4 data; uint32 index; 3 x pad}
+    TOMBSTONE_BITS = 0x7FC0DEAD
+
+    def slab_halo_violation(self) -> bool:
+        v = C.c_uint32()
+        self._check(self._lib.fluid_slab_status(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def particles_collect_leavers(self):
+        """Returns (device pointer of the leaver list, count)."""
+        ptr, n = C.c_void_p(), C.c_uint32()
+        self._check(self._lib.fluid_particles_collect_leavers(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def particles_adopt(self, device_ptr: int, count: int):
+        self._check(self._lib.fluid_particles_adopt(self._h, device_ptr, count))
 
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))

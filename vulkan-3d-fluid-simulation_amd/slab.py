@@ -74,12 +74,13 @@ class GpuSlabCompute:
     planes as tensor views) handed to the engine as its arena; kernels run on torch's current
     stream, which is also the stream the NCCL ops synchronise with."""
 
-    def __init__(self, params: FluidParams, slab: Tuple[int, int], device, pressure_kernel: int = 0):
+    def __init__(self, params: FluidParams, slab: Tuple[int, int], device, pressure_kernel: int = 0,
+                 particle_capacity: int = 0, pressure_iterations: int = 200):
         import torch
 
         self.torch = torch
         self.device = device
-        nbytes = E.FluidEngine.required_arena_bytes(params, 0, slab=slab)
+        nbytes = E.FluidEngine.required_arena_bytes(params, particle_capacity, slab=slab)
         if nbytes == 0:
             raise RuntimeError("invalid slab geometry")
         # One explicit side stream, made torch's current stream for this process: the engine's
@@ -92,7 +93,8 @@ class GpuSlabCompute:
         self._pad = (-base) % 256
         assert self.stream.cuda_stream != 0
         self.engine = E.FluidEngine(
-            params, particle_capacity=0, device=device.index if device.index is not None else -1,
+            params, particle_capacity=particle_capacity, pressure_iterations=pressure_iterations,
+            device=device.index if device.index is not None else -1,
             slab=slab, stream=self.stream.cuda_stream,
             arena=base + self._pad, arena_bytes=nbytes)
         self.engine.set_option(E.OPT_PRESSURE_KERNEL, pressure_kernel)
@@ -169,6 +171,32 @@ class GpuSlabCompute:
 
     def halo_written(self, image_id: int):
         self.engine.notify_image_written(image_id)
+
+    # ---- full step on slabs -----------------------------------------------------------------------
+    IMAGE_GHOST = E.FluidEngine.IMAGE_GHOST_PLANES
+
+    def run_section(self, name: str):
+        self.engine.run_section(name)
+
+    def image_planes(self, image_id: int, first: int, count: int):
+        """`count` consecutive local planes of an image as one flat tensor."""
+        ptr, nbytes = self.engine.image_plane_ptr(image_id, first)
+        dtype, _ = E.IMAGE_DTYPES[image_id]
+        return self._view(ptr, nbytes * count, dtype == np.float32)
+
+    def collect_leavers(self):
+        """Particles that left this slab in 14_particles: (uint8 tensor of 32-byte entries, count)."""
+        ptr, n = self.engine.particles_collect_leavers()
+        if n == 0:
+            return self.arena[:0], 0
+        return self._view(ptr, n * self.engine.LEAVER_BYTES, False), n
+
+    def adopt(self, entries, count: int):
+        if count:
+            self.engine.particles_adopt(entries.data_ptr(), count)
+
+    def halo_violation(self) -> bool:
+        return self.engine.slab_halo_violation()
 
     def close(self):
         self.engine.close()
@@ -471,6 +499,142 @@ class SlabPressureSolver:
             dist.gather_object(local.numpy(), parts, dst=0)
             res.append(np.concatenate(parts, axis=0) if self.ctx.rank == 0 else None)
         return res
+
+    def close(self):
+        self.compute.close()
+
+
+# ---- the whole simulation step on Z slabs ---------------------------------------------------------------
+class SlabSimulation:
+    """SimulationInitializationSections / SimulationStepSections (fluid_flow_sections.h:136-338) with
+    the grid cut into Z slabs, one rank per slab: the reference's section order, plus the ghost-plane
+    exchanges the stencils and the velocity sampler need and the hand-over of particles that cross a
+    slab face (include/fluid_engine.h, "Z-slab contexts, full step").  Results equal the single-GPU
+    (and the oracle's) step bit for bit as long as no sample reaches further than the ghost planes
+    (checked every step)."""
+
+    def __init__(self, params: FluidParams, particle_capacity: int, iterations: int, ctx: DistContext,
+                 compute=None, transport: str = "direct", halo_depth: int = 8):
+        self.params = params
+        self.ctx = ctx
+        self.size = params.size
+        self.capacity = particle_capacity
+        slab = partition_z(self.size[2], ctx.world)[ctx.rank]
+        self.slab = slab
+        self.compute = compute or GpuSlabCompute(params, slab, ctx.device,
+                                                 particle_capacity=particle_capacity,
+                                                 pressure_iterations=iterations)
+        self.pressure = SlabPressureSolver(self.size, iterations, ctx, self.compute, slab,
+                                           transport=transport, halo_depth=halo_depth)
+        self.transport = transport
+        self.ghost = min(self.compute.IMAGE_GHOST, min(n for _, n in partition_z(self.size[2],
+                                                                                  ctx.world)))
+        self.migrated = 0  # particles handed over so far (diagnostics)
+
+    # -- halo exchange of an image, `width` planes deep (reuses the solver's plan machinery)
+    def exchange_image(self, image_id: int, width: int):
+        self.pressure._run_plan(("image", image_id, width),
+                                lambda z, n: self.compute.image_planes(image_id, z, n), width)
+        self.compute.halo_written(image_id)
+
+    def run_init(self):
+        for name in ("init_clear_velocities_1", "init_clear_cell_types", "00_init_particles"):
+            self.compute.run_section(name)
+        # cleared images are uniform, but their value need not be the ghost planes' zero
+        self.exchange_image(E.CELL_TYPES, 1)
+        self.exchange_image(E.VELOCITIES_1, self.ghost)
+
+    def run_step(self):
+        c, x = self.compute, self.exchange_image
+        c.run_section("01a_clear_particle_densities")
+        c.run_section("01_update_densities")          # owned particles only, into owned planes
+        c.run_section("02_update_water")
+        x(E.NEW_CELL_TYPES, 1)                         # 03 looks at z-1 / z+1
+        c.run_section("03_update_air")
+        x(E.NEW_CELL_TYPES, 1)                         # 05 reads the final new types at z-1
+        c.run_section("04_compute_extrapolated_velocities")  # old types / V1 at z+-1: still current
+        c.run_section("05_set_extrapolated_velocities")
+        x(E.VELOCITIES_1, self.ghost)                  # 07 samples V1 around each cell
+        c.run_section("06_update_cell_types")          # carries one ghost plane per side along
+        c.run_section("07_advect")
+        c.run_section("08_forces")
+        c.run_section("09_diffuse")
+        c.run_section("10_solids")
+        x(E.VELOCITIES_1, 1)                           # 11 reads V1 at z+1
+        c.run_section("11_compute_divergence")
+        self.pressure.step()                           # 12a, 12b, the 12_solve_pressure loop
+        x(E.PRESSURES_2, 1)                            # 13 reads P2 at z-1
+        c.run_section("13_fix_divergence")
+        x(E.VELOCITIES_1, self.ghost)                  # 14 samples V1; 04 of the next step reads z+-1
+        c.run_section("14_particles")
+        self.migrate_particles()
+        if c.halo_violation():
+            raise RuntimeError("a velocity sample reached beyond the ghost planes of this slab "
+                               f"({self.ghost} planes): the fluid moves too fast for the slab halo")
+
+    # -- particles that crossed a slab face change owner
+    def migrate_particles(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.ctx.world == 1 or self.capacity == 0:
+            return
+        entries, n = self.compute.collect_leavers()
+        staged = self.transport == "staged" or self.ctx.backend == "gloo"
+        dev = torch.device("cpu") if staged else self.ctx.device
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.ctx.world)]
+        dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
+        counts = [int(t.item()) for t in counts]
+        most = max(counts)
+        if most == 0:
+            return
+        width = most * E.FluidEngine.LEAVER_BYTES
+        send = torch.zeros(width, dtype=torch.uint8, device=dev)
+        if n:
+            send[:n * E.FluidEngine.LEAVER_BYTES] = entries.to(dev)
+        gathered = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(self.ctx.world)]
+        dist.all_gather(gathered, send)
+        for r, cnt in enumerate(counts):
+            if cnt and r != self.ctx.rank:
+                self.compute.adopt(gathered[r].to(self.ctx.device) if staged else gathered[r], cnt)
+        self.migrated += sum(counts)
+        self.compute.sync()  # the gathered buffers are released when this returns
+
+    # -- global state in (checkpoint restore): every rank passes the same global array
+    def upload_image_global(self, image_id: int, array: np.ndarray):
+        z0, n = self.slab
+        self.compute.upload(image_id, np.ascontiguousarray(array[z0:z0 + n]))
+        self.exchange_image(image_id, self.ghost)
+
+    def upload_particles_global(self, particles: np.ndarray):
+        self.compute.engine.upload_particles(particles)  # the engine keeps the slots this slab owns
+
+    # -- global views (tests, checkpoints): rank 0 gets the arrays, the others None
+    def gather_image(self, image_id: int):
+        import torch.distributed as dist
+
+        local = self.compute.download(image_id)
+        parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
+        dist.gather_object(local, parts, dst=0)
+        return np.concatenate(parts, axis=0) if self.ctx.rank == 0 else None
+
+    def gather_particles(self):
+        import torch.distributed as dist
+
+        local = self.compute.engine.download_particles()
+        parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
+        dist.gather_object(local, parts, dst=0)
+        if self.ctx.rank != 0:
+            return None
+        out = np.zeros_like(parts[0])
+        owners = np.zeros(out.shape[0], np.int32)
+        for arr in parts:
+            real = arr.view(np.uint32)[:, 3] != E.FluidEngine.TOMBSTONE_BITS
+            out[real] = arr[real]
+            owners += real
+        if not np.all(owners == 1):
+            raise RuntimeError(f"{int(np.sum(owners != 1))} particle slots do not have exactly one owner")
+        return out
 
     def close(self):
         self.compute.close()
