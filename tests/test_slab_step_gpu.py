@@ -66,6 +66,7 @@ def _worker(rank, world, port, size, iters, steps, out_dir):
     params, cap = scene_params(size)
     sim = SlabSimulation(params, cap, iters, ctx, transport="staged")
     sim.run_init()
+    sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
     for _ in range(steps):
         sim.run_step()
@@ -95,6 +96,7 @@ def test_slab_simulation_matches_oracle(world, size, iters, steps, tmp_path):
     params, cap = scene_params(size)
     st = OracleState(params, cap, iters)
     st.run_init()
+    st.run_step()
     st.velocities_1[...] = drift(st.shape)
     for _ in range(steps):
         st.run_step()

@@ -198,6 +198,12 @@ class GpuSlabCompute:
     def halo_violation(self) -> bool:
         return self.engine.slab_halo_violation()
 
+    def download_particles(self) -> np.ndarray:
+        return self.engine.download_particles()
+
+    def upload_particles(self, particles: np.ndarray):
+        self.engine.upload_particles(particles)
+
     def close(self):
         self.engine.close()
 
@@ -607,7 +613,7 @@ class SlabSimulation:
         self.exchange_image(image_id, self.ghost)
 
     def upload_particles_global(self, particles: np.ndarray):
-        self.compute.engine.upload_particles(particles)  # the engine keeps the slots this slab owns
+        self.compute.upload_particles(particles)  # the backend keeps the slots this slab owns
 
     # -- global views (tests, checkpoints): rank 0 gets the arrays, the others None
     def gather_image(self, image_id: int):
@@ -621,7 +627,7 @@ class SlabSimulation:
     def gather_particles(self):
         import torch.distributed as dist
 
-        local = self.compute.engine.download_particles()
+        local = self.compute.download_particles()
         parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
         dist.gather_object(local, parts, dst=0)
         if self.ctx.rank != 0:
