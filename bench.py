@@ -124,6 +124,33 @@ def full_step_bench(size, iters, steps, device):
     }
 
 
+def slab_full_step_bench(size, iters, steps, dist_ctx):
+    """Full simulation steps/sec on Z slabs (slab.SlabSimulation), dam-break scene."""
+    import torch.distributed as dist
+
+    import fluid_amd
+    from fluid_amd.slab import SlabSimulation
+
+    p, cap = fluid_amd.dam_break_params(*size)
+    sim = SlabSimulation(p, cap, iters, dist_ctx)
+    sim.run_init()
+    for _ in range(2):
+        sim.run_step()
+    sim.compute.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.run_step()
+    sim.compute.sync()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    sim.close()
+    return {"workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi "
+                        f"iters, Z slabs over {dist_ctx.world} GPUs",
+            "steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "particles_migrated": sim.migrated}
+
+
 def main():
     args = parse_args()
     size = grid_dims(args.grid)
@@ -145,12 +172,20 @@ def main():
     if not os.path.exists(E.LIB_PATH):
         fluid_amd.build_engine()
 
-    if world > 1:
+    if world > 1 or os.environ.get("FLUID_BENCH_FORCE_SLAB") == "1":  # (the env var: tests only)
         from fluid_amd.slab import SlabPressureSolver, init_distributed
         dist_ctx = init_distributed(local_rank)
         solver = SlabPressureSolver.create_gpu(size, args.iters, dist_ctx,
                                                pressure_kernel=args.pressure_kernel)
         result = solver.benchmark(args.steps, args.warmup)
+        halo = solver.effective_halo()
+        solver.close()
+        full = None
+        if not args.no_full_step:
+            try:
+                full = slab_full_step_bench(size, args.iters, args.full_step_steps, dist_ctx)
+            except Exception as exc:  # the headline metric above must survive a failure here
+                full = {"error": f"{type(exc).__name__}: {exc}"}
         if rank == 0:
             cells = w * h * d
             sweeps = args.steps * args.iters
@@ -176,10 +211,12 @@ def main():
                              "kernel": "k12_canon (per GPU, slab)",
                              "kernel_ms": kernel_ms},
                 "halo_exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
+                "halo_depth": halo,
                 "cells_per_sec": cells * sweeps / wall,
             }
+            if full is not None:
+                out["full_step"] = full
             print(json.dumps(out), flush=True)
-        solver.close()
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
