@@ -83,7 +83,10 @@ struct fluid_ctx {
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
-    uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter
+    uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter,
+                                          // [2] bricks holding water
+    uint32_t* brick_count_host = nullptr; // pinned; written by an async copy after k12_prepare, read
+                                          // one loop later as a launch-shaping hint (may be stale)
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
     uint32_t leavers_capacity = 0;
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
@@ -276,6 +279,7 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
 
 dim3 cell_block() { return dim3(64, 4, 1); }
 dim3 cell_grid(const GridK& g) { return dim3((g.W + 63) / 64, (g.H + 3) / 4, g.Dl); }
+dim3 cell4_grid(const GridK& g) { return dim3((g.W / 4 + 63) / 64, (g.H + 3) / 4, g.Dl); }
 
 // ---- timing ----------------------------------------------------------------------------------
 int fold_timers(fluid_ctx* c) {
@@ -417,20 +421,34 @@ int ensure_prepared(fluid_ctx* c) {
     if (c->mask_valid && c->rhs_valid) return FLUID_OK;
     const GridK& g = c->g;
     if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
-    k12_launch_prepare(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
-                       c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(), c->bricks(), g,
-                       c->pk, !c->mask_valid, !c->rhs_valid);
+    // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
+    k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                          c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
+                          c->bricks(), g, c->pk, !c->mask_valid, !c->rhs_valid);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = c->rhs_valid = true;
+    if (c->brick_count_host) {
+        k12_launch_count_bricks(c->stream, c->bricks(), (int)c->active_bytes, c->flags() + 2);
+        HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 4, hipMemcpyDeviceToHost,
+                                  c->stream));
+    }
     return FLUID_OK;
 }
 // Import / background cover the owned planes; ghost planes of the working buffers are filled by the
 // caller's halo exchange (whole planes, so their non-water constants arrive with them).
 int import_pressures(fluid_ctx* c, int image, int w) {
-    k12_launch_import(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
-                      c->work0(w), c->g, c->pk, 0, c->g.Dl);
+    // one pass also lays down the constants of the other two buffers when they are stale
+    float* others[2] = {nullptr, nullptr};
+    int n = 0;
+    for (int i = 0; i < 3; i++)
+        if (i != w) {
+            if (!c->bg_valid[i]) others[n] = c->work0(i);
+            n++;
+        }
+    k12_launch_import_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
+                         c->work0(w), others[0], others[1], c->g, c->pk);
     HIP_TRY(c, hipGetLastError());
-    c->bg_valid[w] = true;
+    c->bg_valid[0] = c->bg_valid[1] = c->bg_valid[2] = true;
     return FLUID_OK;
 }
 int ensure_background(fluid_ctx* c, int w) {
@@ -442,10 +460,11 @@ int ensure_background(fluid_ctx* c, int w) {
     return FLUID_OK;
 }
 int export_pressures(fluid_ctx* c, int w_even, int w_odd) {
-    k12_launch_export(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
-                      w_even >= 0 ? c->work0(w_even) : nullptr,
-                      w_odd >= 0 ? c->work0(w_odd) : nullptr, c->plane0<float>(FLUID_IMG_PRESSURES_1),
-                      c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
+    k12_launch_export_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                         w_even >= 0 ? c->work0(w_even) : nullptr,
+                         w_odd >= 0 ? c->work0(w_odd) : nullptr,
+                         c->plane0<float>(FLUID_IMG_PRESSURES_1),
+                         c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -468,7 +487,10 @@ int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
     HIP_TRY(c, k12_launch_canon2(c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
                                  mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
                                  oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
-                                 lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0));
+                                 lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0,
+                                 c->brick_count_host && *c->brick_count_host != 0xFFFFFFFFu
+                                     ? (float)*c->brick_count_host / (float)c->active_bytes
+                                     : -1.0f));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -597,10 +619,18 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         }
         case FLUID_SEC_02_UPDATE_WATER:
-            hipLaunchKernelGGL(k02_update_water, grid, block, 0, c->stream, dens, newT, g, pk);
+            if (g.W % 4 == 0)
+                hipLaunchKernelGGL(k02_update_water_v4, cell4_grid(g), block, 0, c->stream, dens,
+                                   newT, g, pk);
+            else
+                hipLaunchKernelGGL(k02_update_water, grid, block, 0, c->stream, dens, newT, g, pk);
             break;
         case FLUID_SEC_03_UPDATE_AIR:
-            hipLaunchKernelGGL(k03_update_air, grid, block, 0, c->stream, newT, g, pk);
+            if (g.W % 4 == 0)
+                hipLaunchKernelGGL(k03_update_air_v4, cell4_grid(g), block, 0, c->stream, newT, g,
+                                   pk);
+            else
+                hipLaunchKernelGGL(k03_update_air, grid, block, 0, c->stream, newT, g, pk);
             break;
         case FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES:
             hipLaunchKernelGGL(k04_extrapolated, grid, block, 0, c->stream, T, V1, V2, g, pk);
@@ -860,6 +890,13 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
         c->arena = static_cast<uint8_t*>(ptr);
         c->own_arena = true;
     }
+    {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) {
+            c->brick_count_host = static_cast<uint32_t*>(hp);
+            *c->brick_count_host = 0xFFFFFFFFu;  // unknown
+        }
+    }
     // zero everything once: the ghost planes at the domain faces must read as 0 forever
     if ((e = hipMemsetAsync(c->arena, 0, L.total, c->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
@@ -877,6 +914,7 @@ void fluid_destroy(fluid_ctx* c) {
         if (s.start) (void)hipEventDestroy(s.start);
         if (s.stop) (void)hipEventDestroy(s.stop);
     }
+    if (c->brick_count_host) (void)hipHostFree(c->brick_count_host);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -60,6 +60,70 @@ __global__ void k03_update_air(uint8_t* __restrict__ t, GridK g, ParamsK p) {
     if (w) t[id] = (uint8_t)p.t_air;  // :61-62
 }
 
+// ---- four cells per thread for the byte-sized images (fluid_size.x % 4 == 0) ---------------------
+// 02 / 03 move one byte per cell; one cell per lane means 64-byte accesses per wavefront.  Here a lane
+// handles four consecutive cells: 16-byte density loads, 4-byte type words.
+#define FLUID_CELL4_THREAD()                                        \
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);      \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;            \
+    const int lz = blockIdx.z;                                      \
+    if (x >= g.W || y >= g.H) return;                               \
+    const int64_t id = cidx(g, x, y, lz);                           \
+    const int gz = g.z0 + lz;
+
+__global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* __restrict__ newT,
+                                    GridK g, ParamsK p) {
+    FLUID_CELL4_THREAD();
+    (void)gz;
+    const uint4 d = *reinterpret_cast<const uint4*>(dens + id);
+    const uint32_t a = d.x > 0u ? p.t_water : p.t_inactive, b = d.y > 0u ? p.t_water : p.t_inactive;
+    const uint32_t c = d.z > 0u ? p.t_water : p.t_inactive, e = d.w > 0u ? p.t_water : p.t_inactive;
+    *reinterpret_cast<uint32_t*>(newT + id) = a | (b << 8) | (c << 16) | (e << 24);
+}
+
+__global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p) {
+    FLUID_CELL4_THREAD();
+    auto word = [&](int yy, int llz) -> uint32_t {  // interior rows only: always inside the image
+        return *reinterpret_cast<const uint32_t*>(t + cidx(g, x, yy, llz));
+    };
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+    const bool row_border = y == 0 || y == g.H - 1 || gz == 0 || gz == g.Dg - 1;
+    uint32_t out = 0;
+    if (row_border) {
+        out = p.t_solid * 0x01010101u;  // update_active.comp:50-51
+    } else {
+        // neighbours on the domain border never count as water ("solid first")
+        const bool ym_b = y - 1 == 0, yp_b = y + 1 == g.H - 1, zm_b = gz - 1 == 0,
+                   zp_b = gz + 1 == g.Dg - 1;
+        const uint32_t ym = word(y - 1, lz), yp = word(y + 1, lz);
+        const uint32_t zm = word(y, lz - 1), zp = word(y, lz + 1);
+        const uint32_t left = x > 0 ? (uint32_t)t[id - 1] : 0u;
+        const uint32_t right = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int xi = x + i;
+            const uint32_t self = (c >> (8 * i)) & 0xFFu;
+            uint32_t r = self;
+            if (xi == 0 || xi == g.W - 1) {
+                r = p.t_solid;
+            } else if (self != p.t_water) {  // :54
+                const uint32_t xm = i == 0 ? left : (c >> (8 * (i - 1))) & 0xFFu;
+                const uint32_t xp = i == 3 ? right : (c >> (8 * ((i + 1) & 3))) & 0xFFu;
+                bool w = false;
+                w = w || (xi + 1 != g.W - 1 && xp == p.t_water);
+                w = w || (!yp_b && ((yp >> (8 * i)) & 0xFFu) == p.t_water);
+                w = w || (!zp_b && ((zp >> (8 * i)) & 0xFFu) == p.t_water);
+                w = w || (xi - 1 != 0 && xm == p.t_water);
+                w = w || (!ym_b && ((ym >> (8 * i)) & 0xFFu) == p.t_water);
+                w = w || (!zm_b && ((zm >> (8 * i)) & 0xFFu) == p.t_water);
+                if (w) r = p.t_air;  // :61-62
+            }
+            out |= r << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(t + id) = out;
+}
+
 // 04_compute_extrapolated_velocities/extrapolated_velocities.comp:37-63
 __global__ void k04_extrapolated(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                                  float4* __restrict__ v2, GridK g, ParamsK p) {

@@ -278,6 +278,22 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
     }
 }
 
+// number of bricks that hold water (one small workgroup; the host uses it, one loop late, to shape the
+// launches of sparse scenes)
+__global__ void k12_count_bricks(const uint8_t* __restrict__ active, int n,
+                                 uint32_t* __restrict__ count) {
+    __shared__ uint32_t partial[256];
+    uint32_t c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += active[i] ? 1u : 0u;
+    partial[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) partial[threadIdx.x] += partial[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = partial[0];
+}
+
 // PRESSURES_1 -> working buffer (all planes incl. ghosts that hold neighbour slabs' cells)
 __global__ void k12_import(const uint8_t* __restrict__ t, const float* __restrict__ pimg,
                            float* __restrict__ work, GridK g, ParamsK p, int lz0) {

@@ -1,0 +1,120 @@
+// kernels_pressure_passes.h — the once-per-loop passes around the 12_solve_pressure sweeps (build the
+// neighbour mask / b_i, import PRESSURES_1 into the working buffers, export the result), four cells per
+// thread: cell types move as 4-byte words and pressures as 16-byte vectors, so these passes stream at
+// the HBM rate instead of issuing one byte load per lane.  Same arithmetic as the one-cell-per-thread
+// kernels in kernels_pressure.h (which remain the path for widths that are not a multiple of 4).
+#pragma once
+
+#include "pressure_common.h"
+
+namespace fluid {
+
+__device__ __forceinline__ uint32_t ld_types4(const uint8_t* __restrict__ t, const GridK& g, int x,
+                                              int y, int lz) {
+    // four cell types starting at x (x % 4 == 0, W % 4 == 0); a row outside the grid reads as 0
+    if ((unsigned)x >= (unsigned)g.W || (unsigned)y >= (unsigned)g.H) return 0u;
+    return *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz));
+}
+__device__ __forceinline__ uint32_t byte_at(uint32_t w, int i) { return (w >> (8 * i)) & 0xFFu; }
+
+#define FLUID_V4_THREAD()                                          \
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);     \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;           \
+    if (x >= g.W || y >= g.H) return;
+
+// mask byte + b_i + activity bricks (k12_prepare of kernels_pressure.h, four cells per thread)
+__global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __restrict__ div,
+                               uint8_t* __restrict__ mask, float* __restrict__ rhs,
+                               uint8_t* __restrict__ active, BrickK bk, GridK g, ParamsK p,
+                               int do_mask, int do_rhs) {
+    FLUID_V4_THREAD();
+    const int lz = blockIdx.z;
+    const int64_t id = cidx(g, x, y, lz);
+    if (do_rhs) {
+        const float4 d = *reinterpret_cast<const float4*>(div + id);
+        float4 b;
+        b.x = ((d.x * p.rho) * p.dx) / p.dt;  // pressure.comp:54
+        b.y = ((d.y * p.rho) * p.dx) / p.dt;
+        b.z = ((d.z * p.rho) * p.dx) / p.dt;
+        b.w = ((d.w * p.rho) * p.dx) / p.dt;
+        *reinterpret_cast<float4*>(rhs + id) = b;
+    }
+    if (do_mask) {
+        const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+        const uint32_t yp = ld_types4(t, g, x, y + 1, lz), ym = ld_types4(t, g, x, y - 1, lz);
+        const uint32_t zp = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz + 1));
+        const uint32_t zm = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz - 1));
+        const uint32_t left = x > 0 ? (uint32_t)t[id - 1] : 0u;
+        const uint32_t right = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+        uint32_t out = 0;
+        bool any_water = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t xm = i == 0 ? left : byte_at(c, i == 0 ? 0 : i - 1);
+            const uint32_t xp = i == 3 ? right : byte_at(c, i == 3 ? 3 : i + 1);
+            uint32_t m = 0;
+            m += xp != p.t_solid ? 1u : 0u;
+            m += byte_at(yp, i) != p.t_solid ? 1u : 0u;
+            m += byte_at(zp, i) != p.t_solid ? 1u : 0u;
+            m += xm != p.t_solid ? 1u : 0u;
+            m += byte_at(ym, i) != p.t_solid ? 1u : 0u;
+            m += byte_at(zm, i) != p.t_solid ? 1u : 0u;
+            const bool water = byte_at(c, i) == p.t_water;
+            any_water = any_water || water;
+            out |= (water ? m : MASK_DRY) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(mask + id) = out;
+        // same value from every writer: a benign race (the array was zeroed before this launch)
+        if (any_water) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
+    }
+}
+
+// PRESSURES_1 -> working buffer w0 (water: its value, else the cell's constant) and, where given, the
+// constants of the other two working buffers (their water cells are written by the sweeps)
+__global__ void k12_import_v4(const uint8_t* __restrict__ t, const float* __restrict__ pimg,
+                              float* __restrict__ w0, float* __restrict__ w1,
+                              float* __restrict__ w2, GridK g, ParamsK p) {
+    FLUID_V4_THREAD();
+    const int64_t id = cidx(g, x, y, (int)blockIdx.z);
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+    const float4 v = *reinterpret_cast<const float4*>(pimg + id);
+    const float bg[4] = {background_value(byte_at(c, 0), p), background_value(byte_at(c, 1), p),
+                         background_value(byte_at(c, 2), p), background_value(byte_at(c, 3), p)};
+    float4 o;
+    o.x = byte_at(c, 0) == p.t_water ? v.x : bg[0];
+    o.y = byte_at(c, 1) == p.t_water ? v.y : bg[1];
+    o.z = byte_at(c, 2) == p.t_water ? v.z : bg[2];
+    o.w = byte_at(c, 3) == p.t_water ? v.w : bg[3];
+    *reinterpret_cast<float4*>(w0 + id) = o;
+    const float4 b4 = make_float4(bg[0], bg[1], bg[2], bg[3]);
+    if (w1) *reinterpret_cast<float4*>(w1 + id) = b4;
+    if (w2) *reinterpret_cast<float4*>(w2 + id) = b4;
+}
+
+// working buffers -> water cells of PRESSURES_1 (even iterate) and PRESSURES_2 (odd iterate)
+__global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __restrict__ w_even,
+                              const float* __restrict__ w_odd, float* __restrict__ p1,
+                              float* __restrict__ p2, GridK g, ParamsK p) {
+    FLUID_V4_THREAD();
+    const int64_t id = cidx(g, x, y, (int)blockIdx.z);
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+    const bool w[4] = {byte_at(c, 0) == p.t_water, byte_at(c, 1) == p.t_water,
+                       byte_at(c, 2) == p.t_water, byte_at(c, 3) == p.t_water};
+    if (!(w[0] || w[1] || w[2] || w[3])) return;  // pressure.comp:69: non-water cells are never written
+    const bool all = w[0] && w[1] && w[2] && w[3];
+    auto put = [&](const float* src, float* dst) {
+        const float4 v = *reinterpret_cast<const float4*>(src + id);
+        if (all) {
+            *reinterpret_cast<float4*>(dst + id) = v;
+        } else {
+            if (w[0]) dst[id] = v.x;
+            if (w[1]) dst[id + 1] = v.y;
+            if (w[2]) dst[id + 2] = v.z;
+            if (w[3]) dst[id + 3] = v.w;
+        }
+    };
+    if (w_even) put(w_even, p1);
+    if (w_odd) put(w_odd, p2);
+}
+
+}  // namespace fluid

@@ -28,6 +28,16 @@ void k12_launch_zmarch(hipStream_t s, int rows_per_wave, const uint8_t* t, const
 // loop section on working buffers
 void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask, float* rhs,
                         uint8_t* bricks, const GridK& g, const ParamsK& p, bool do_mask, bool do_rhs);
+// four-cells-per-thread forms of prepare / import (+ constants of the other buffers) / export, for
+// fluid_size.x % 4 == 0 (pressure_passes.hip)
+void k12_launch_prepare_v4(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask,
+                           float* rhs, uint8_t* bricks, const GridK& g, const ParamsK& p,
+                           bool do_mask, bool do_rhs);
+void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, float* w0, float* w1,
+                          float* w2, const GridK& g, const ParamsK& p);
+void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
+                          float* p1, float* p2, const GridK& g, const ParamsK& p);
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, int n, uint32_t* count);
 void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
                        const GridK& g, const ParamsK& p, int lz0, int nplanes);
 void k12_launch_background(hipStream_t s, const uint8_t* t, float* work, const GridK& g,
@@ -40,7 +50,8 @@ void k12_launch_canon(hipStream_t s, int rows_per_wave, const uint8_t* mask, con
 // two sweeps per pass; returns a hipError_t from the one-time LDS attribute call (hipSuccess else)
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi);
+                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
+                             float active_fraction);
 bool k12_canon2_supports(const GridK& g);
 
 }  // namespace fluid

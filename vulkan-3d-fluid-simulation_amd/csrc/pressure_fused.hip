@@ -51,6 +51,15 @@ static int pick_zchunk(int row_groups, int depth, int cus) {
     return best;
 }
 
+static int sparse_zchunk() {  // tuning aid: FLUID_SPARSE_ZCHUNK
+    static int v = 0;
+    if (v == 0) {
+        const char* e = getenv("FLUID_SPARSE_ZCHUNK");
+        v = e ? std::max(2, atoi(e)) : 16;
+    }
+    return v;
+}
+
 static int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -66,7 +75,7 @@ static int cu_count() {
 template <int NT>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                            float p_oob, const FusedRange& rg) {
+                            float p_oob, const FusedRange& rg, float active_fraction) {
     static bool attr_set = false;  // per process and instantiation; the attribute is per function
     const size_t lds = fused_lds_bytes(NT);
     if (!attr_set) {
@@ -79,6 +88,11 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     const int by = (g.H + TY - 1) / TY;
     const int depth = rg.zout_hi - rg.zout_lo;
     int zchunk = pick_zchunk(by, depth, cu_count());
+    // Sparse scene (few bricks hold water): most workgroups leave at once and the few that work
+    // should be short, so that they run side by side instead of one long march per CU.
+    if (active_fraction >= 0.f &&
+        active_fraction * by * ((depth + zchunk - 1) / zchunk) < 0.75f * cu_count())
+        zchunk = std::min(zchunk, sparse_zchunk());
     if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
     const dim3 grid(1, by, (depth + zchunk - 1) / zchunk);
     BrickK bk;
@@ -92,7 +106,8 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
 
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi) {
+                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
+                             float active_fraction) {
     // halo_lo / halo_hi: valid ghost planes of the input below / above the owned planes (0 at a
     // domain face); aux_*: the same for mask and b_i.  A launch consumes two planes of halo.
     FusedRange rg;
@@ -103,9 +118,9 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.zout_lo = -std::max(0, std::min(halo_lo - 2, aux_lo - 1));
     rg.zout_hi = g.Dl + std::max(0, std::min(halo_hi - 2, aux_hi - 1));
     const int nt = (g.W + 255) / 256;
-    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
-    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
-    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg);
+    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
+    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
+    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
     return hipErrorInvalidValue;
 }
 

@@ -56,6 +56,10 @@ void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8
                        bricks, bricks_of(g), g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0);
 }
 
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, int n, uint32_t* count) {
+    hipLaunchKernelGGL(k12_count_bricks, dim3(1), dim3(256), 0, s, bricks, n, count);
+}
+
 void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
                        const GridK& g, const ParamsK& p, int lz0, int nplanes) {
     hipLaunchKernelGGL(k12_import, cell_grid(g, nplanes), cell_block(), 0, s, t, pimg, work, g, p,
