@@ -85,8 +85,10 @@ struct fluid_ctx {
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
     uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter,
                                           // [2] bricks holding water
-    uint32_t* brick_count_host = nullptr; // pinned; written by an async copy after k12_prepare, read
-                                          // one loop later as a launch-shaping hint (may be stale)
+    uint32_t* brick_count_host = nullptr; // pinned, 5 words (k12_count_bricks); written by an async
+                                          // copy after k12_prepare
+    bool box_pending = false;             // that copy has been enqueued and not been waited for
+    ActiveBox box;                        // where the water is, for launch shaping
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
     uint32_t leavers_capacity = 0;
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
@@ -420,18 +422,38 @@ float oob_value(const fluid_ctx* c) {
 int ensure_prepared(fluid_ctx* c) {
     if (c->mask_valid && c->rhs_valid) return FLUID_OK;
     const GridK& g = c->g;
-    if (!c->mask_valid) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
+    const bool rebuilt_mask = !c->mask_valid;
+    if (rebuilt_mask) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
                           c->bricks(), g, c->pk, !c->mask_valid, !c->rhs_valid);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = c->rhs_valid = true;
-    if (c->brick_count_host) {
-        k12_launch_count_bricks(c->stream, c->bricks(), (int)c->active_bytes, c->flags() + 2);
-        HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 4, hipMemcpyDeviceToHost,
+    if (c->brick_count_host && rebuilt_mask) {
+        k12_launch_count_bricks(c->stream, c->bricks(), g, c->flags() + 2);
+        HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 20, hipMemcpyDeviceToHost,
                                   c->stream));
+        c->box_pending = true;
+        c->box.valid = false;  // fraction: the previous loop's, a hint until refresh_box()
     }
+    return FLUID_OK;
+}
+// Wait for the brick summary of the current mask (one stream synchronisation per rebuilt mask, i.e.
+// per step; a whole-grid loop of N sweeps follows) and turn it into the launch box.
+int refresh_box(fluid_ctx* c) {
+    if (!c->box_pending) return FLUID_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->box_pending = false;
+    const uint32_t* h = c->brick_count_host;
+    int bx, by, bz;
+    k12_brick_cells(bx, by, bz);
+    c->box.valid = true;
+    c->box.fraction = (float)h[0] / (float)c->active_bytes;
+    c->box.y_lo = (int)h[1] * by;
+    c->box.y_hi = std::min((int)h[2] * by, c->g.H);
+    c->box.z_lo = (int)h[3] * bz;
+    c->box.z_hi = std::min((int)h[4] * bz, c->g.Dl);
     return FLUID_OK;
 }
 // Import / background cover the owned planes; ghost planes of the working buffers are filled by the
@@ -488,9 +510,7 @@ int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
                                  mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
                                  oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
                                  lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0,
-                                 c->brick_count_host && *c->brick_count_host != 0xFFFFFFFFu
-                                     ? (float)*c->brick_count_host / (float)c->active_bytes
-                                     : -1.0f));
+                                 c->box));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -567,6 +587,7 @@ int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
     if (iterations == 0) return FLUID_OK;
     int rc = loop_begin(c);
     const bool fuse = fuse_enabled(c) && !c->is_slab;  // a slab needs its halos between launches
+    if (rc == FLUID_OK && fuse && iterations >= 16) rc = refresh_box(c);
     while (rc == FLUID_OK && c->loop_k < iterations) {
         const uint32_t left = iterations - c->loop_k;
         if (fuse && left >= 2)
@@ -894,7 +915,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) {
             c->brick_count_host = static_cast<uint32_t*>(hp);
-            *c->brick_count_host = 0xFFFFFFFFu;  // unknown
+            memset(hp, 0, 64);
         }
     }
     // zero everything once: the ghost planes at the domain faces must read as 0 forever

@@ -278,20 +278,38 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
     }
 }
 
-// number of bricks that hold water (one small workgroup; the host uses it, one loop late, to shape the
-// launches of sparse scenes)
-__global__ void k12_count_bricks(const uint8_t* __restrict__ active, int n,
-                                 uint32_t* __restrict__ count) {
-    __shared__ uint32_t partial[256];
-    uint32_t c = 0;
-    for (int i = threadIdx.x; i < n; i += 256) c += active[i] ? 1u : 0u;
-    partial[threadIdx.x] = c;
+// Summary of the activity bricks for the host (one small workgroup): out[0] = bricks that hold water,
+// out[1..2] = [lo, hi) brick range in y that holds them, out[3..4] = the same in z (lo = hi = 0 when no
+// brick holds water).  The host shapes the launches of sparse scenes with it.
+__global__ void k12_count_bricks(const uint8_t* __restrict__ active, BrickK bk,
+                                 uint32_t* __restrict__ out) {
+    __shared__ uint32_t sh[5];
+    if (threadIdx.x < 5) sh[threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) partial[threadIdx.x] += partial[threadIdx.x + s];
-        __syncthreads();
+    const int n = bk.nbx * bk.nby * bk.nbz;
+    uint32_t c = 0, ylo = 0xFFFFFFFFu, yhi = 0, zlo = 0xFFFFFFFFu, zhi = 0;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (active[i]) {
+            const uint32_t by = (uint32_t)((i / bk.nbx) % bk.nby), bz = (uint32_t)(i / (bk.nbx * bk.nby));
+            c++;
+            ylo = min(ylo, by);
+            yhi = max(yhi, by + 1u);
+            zlo = min(zlo, bz);
+            zhi = max(zhi, bz + 1u);
+        }
+    if (c) {
+        atomicAdd(&sh[0], c);
+        atomicMin(&sh[1], ylo);
+        atomicMax(&sh[2], yhi);
+        atomicMin(&sh[3], zlo);
+        atomicMax(&sh[4], zhi);
     }
-    if (threadIdx.x == 0) *count = partial[0];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        uint32_t v = sh[threadIdx.x];
+        if (sh[0] == 0u) v = 0u;
+        out[threadIdx.x] = v;
+    }
 }
 
 // PRESSURES_1 -> working buffer (all planes incl. ghosts that hold neighbour slabs' cells)

@@ -63,8 +63,10 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
 //                       h sweeps instead of 2 planes every 2 (same bytes, h/2 times fewer messages)
 //   [jlo, jhi)          planes of the input buffer that hold cells of the grid
 //   [mlo, mhi)          same for mask / b_i
+//   ytile0              first row tile of the launch (blockIdx.y = 0); launches of sparse scenes cover
+//                       only the tiles and planes around the water (ActiveBox, pressure_api.h)
 struct FusedRange {
-    int zout_lo, zout_hi, jlo, jhi, mlo, mhi;
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0;
 };
 
 // Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
@@ -240,7 +242,7 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const int tx = wave % NT;
     c.rr = wave / NT;
     c.x0 = tx * 256 + c.lane * 4;
-    const int y0 = blockIdx.y * TY;        // first output row
+    const int y0 = ((int)blockIdx.y + rg.ytile0) * TY;  // first output row
     const int y = y0 - 1 + c.rr;           // this wavefront's row
     c.zb = rg.zout_lo + blockIdx.z * zchunk;
     c.ze = min(c.zb + zchunk, rg.zout_hi);

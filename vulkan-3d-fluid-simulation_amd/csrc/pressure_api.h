@@ -18,6 +18,7 @@ constexpr int LOOP_GHOST = 8;
 
 // activity-brick geometry for a grid (host arithmetic)
 void k12_brick_dims(int W, int H, int Dl, int& nbx, int& nby, int& nbz);
+void k12_brick_cells(int& bx, int& by, int& bz);  // cells per brick along x, y, z
 
 // single dispatch on the images (any state)
 void k12_launch_plain(hipStream_t s, const uint8_t* t, const float* div, const float* pin,
@@ -37,7 +38,16 @@ void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, fl
                           float* w2, const GridK& g, const ParamsK& p);
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
                           float* p1, float* p2, const GridK& g, const ParamsK& p);
-void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, int n, uint32_t* count);
+// out[0..4] = {bricks with water, y brick range lo, hi, z brick range lo, hi}
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out);
+// Where the water is, in cells (whole bricks), as known to the host: rows [y_lo, y_hi) and local planes
+// [z_lo, z_hi) hold every brick with water; `fraction` of all bricks hold water.  valid = false: unknown
+// (launch over the whole grid).
+struct ActiveBox {
+    bool valid = false;
+    int y_lo = 0, y_hi = 0, z_lo = 0, z_hi = 0;
+    float fraction = -1.0f;
+};
 void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
                        const GridK& g, const ParamsK& p, int lz0, int nplanes);
 void k12_launch_background(hipStream_t s, const uint8_t* t, float* work, const GridK& g,
@@ -51,7 +61,7 @@ void k12_launch_canon(hipStream_t s, int rows_per_wave, const uint8_t* mask, con
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                              float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
-                             float active_fraction);
+                             const ActiveBox& box);
 bool k12_canon2_supports(const GridK& g);
 
 }  // namespace fluid

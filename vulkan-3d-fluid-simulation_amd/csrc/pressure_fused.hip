@@ -26,7 +26,8 @@ static int pick_zchunk(int row_groups, int depth, int cus) {
     const double startup = 3.0;
     double best_cost = 1e300;
     int best = std::min(depth, 32);
-    for (int zc = std::min(depth, 16); zc <= std::min(depth, 128); zc++) {
+    for (int zc = std::min(depth, row_groups * (depth / 16) >= cus ? 16 : 6); zc <= std::min(depth, 128);
+         zc++) {
         const int nz = (depth + zc - 1) / zc;
         std::vector<double> busy(cus, 0.0);  // min-heap by finish time
         auto cmp = [](double a, double b) { return a > b; };
@@ -51,15 +52,6 @@ static int pick_zchunk(int row_groups, int depth, int cus) {
     return best;
 }
 
-static int sparse_zchunk() {  // tuning aid: FLUID_SPARSE_ZCHUNK
-    static int v = 0;
-    if (v == 0) {
-        const char* e = getenv("FLUID_SPARSE_ZCHUNK");
-        v = e ? std::max(2, atoi(e)) : 16;
-    }
-    return v;
-}
-
 static int cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -75,7 +67,7 @@ static int cu_count() {
 template <int NT>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                            float p_oob, const FusedRange& rg, float active_fraction) {
+                            float p_oob, const FusedRange& rg, const ActiveBox& box) {
     static bool attr_set = false;  // per process and instantiation; the attribute is per function
     const size_t lds = fused_lds_bytes(NT);
     if (!attr_set) {
@@ -85,14 +77,27 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
         attr_set = true;
     }
     constexpr int TY = FUSED_WAVES / NT - 2;
-    const int by = (g.H + TY - 1) / TY;
-    const int depth = rg.zout_hi - rg.zout_lo;
+    FusedRange r = rg;
+    int ty0 = 0, ty1 = (g.H + TY - 1) / TY;  // row tiles [ty0, ty1)
+    // Sparse scene on a whole-grid context: launch only the tiles whose output rows / planes meet the
+    // bricks that hold water.  The others would leave at once (no water cell to write), but a
+    // workgroup of 16 wavefronts that starts and leaves still costs a slot on a CU.
+    if (box.valid && rg.zout_lo == 0 && rg.zout_hi == g.Dl) {
+        if (box.y_hi <= box.y_lo || box.z_hi <= box.z_lo) return hipSuccess;  // no water at all
+        ty0 = box.y_lo / TY;
+        ty1 = (std::min(box.y_hi, g.H) + TY - 1) / TY;
+        r.zout_lo = std::max(0, box.z_lo);
+        r.zout_hi = std::min(g.Dl, box.z_hi);
+    }
+    r.ytile0 = ty0;
+    const int by = ty1 - ty0;
+    const int depth = r.zout_hi - r.zout_lo;
     int zchunk = pick_zchunk(by, depth, cu_count());
-    // Sparse scene (few bricks hold water): most workgroups leave at once and the few that work
-    // should be short, so that they run side by side instead of one long march per CU.
-    if (active_fraction >= 0.f &&
-        active_fraction * by * ((depth + zchunk - 1) / zchunk) < 0.75f * cu_count())
-        zchunk = std::min(zchunk, sparse_zchunk());
+    // Sparse scene without a box (Z slab: the ghost planes are not covered by the activity map): most
+    // workgroups leave at once and the few that work should be short, so that they run side by side.
+    if (!box.valid && box.fraction >= 0.f &&
+        box.fraction * by * ((depth + zchunk - 1) / zchunk) < 0.75f * cu_count())
+        zchunk = std::min(zchunk, 24);
     if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
     const dim3 grid(1, by, (depth + zchunk - 1) / zchunk);
     BrickK bk;
@@ -100,14 +105,14 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
     bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
     hipLaunchKernelGGL(k12_canon2<NT>, grid, dim3(FUSED_THREADS), lds, s, mask, rhs, pin, pout, pmid,
-                       bricks, bk, g, p_oob, zchunk, rg);
+                       bricks, bk, g, p_oob, zchunk, r);
     return hipSuccess;
 }
 
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                              float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
-                             float active_fraction) {
+                             const ActiveBox& box) {
     // halo_lo / halo_hi: valid ghost planes of the input below / above the owned planes (0 at a
     // domain face); aux_*: the same for mask and b_i.  A launch consumes two planes of halo.
     FusedRange rg;
@@ -117,10 +122,11 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.mhi = g.Dl + aux_hi;
     rg.zout_lo = -std::max(0, std::min(halo_lo - 2, aux_lo - 1));
     rg.zout_hi = g.Dl + std::max(0, std::min(halo_hi - 2, aux_hi - 1));
+    rg.ytile0 = 0;
     const int nt = (g.W + 255) / 256;
-    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
-    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
-    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, active_fraction);
+    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
+    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
+    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
     return hipErrorInvalidValue;
 }
 

@@ -23,6 +23,12 @@ void k12_brick_dims(int W, int H, int Dl, int& nbx, int& nby, int& nbz) {
     nbz = (Dl + BRICK_Z - 1) / BRICK_Z;
 }
 
+void k12_brick_cells(int& bx, int& by, int& bz) {
+    bx = BRICK_X;
+    by = BRICK_Y;
+    bz = BRICK_Z;
+}
+
 void k12_launch_plain(hipStream_t s, const uint8_t* t, const float* div, const float* pin,
                       float* pout, const GridK& g, const ParamsK& p) {
     hipLaunchKernelGGL(k12_plain, cell_grid(g, g.Dl), cell_block(), 0, s, t, div, pin, pout, g, p);
@@ -56,8 +62,10 @@ void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8
                        bricks, bricks_of(g), g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0);
 }
 
-void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, int n, uint32_t* count) {
-    hipLaunchKernelGGL(k12_count_bricks, dim3(1), dim3(256), 0, s, bricks, n, count);
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out) {
+    BrickK bk;
+    k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
+    hipLaunchKernelGGL(k12_count_bricks, dim3(1), dim3(256), 0, s, bricks, bk, out);
 }
 
 void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
