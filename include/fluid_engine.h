@@ -242,6 +242,20 @@ int fluid_run_section(fluid_ctx* ctx, int section_id);
  * SURVEY.md F2).  Only FLUID_SEC_12_SOLVE_PRESSURE is a loop section on this path. */
 int fluid_run_section_loop(fluid_ctx* ctx, int section_id, uint32_t iterations);
 
+/* `count` consecutive entries of SimulationStepSections, starting at `first_section_id`, as one unit
+ * (a FlowSectionList slice, fluid_flow_sections.h:164-338).  Every image holds afterwards what the
+ * sections run one by one would leave, EXCEPT an image that only carries data from one section of
+ * the group to the next and that a later section of the step overwrites completely — the engine may
+ * skip storing it (named per group below).  Groups with a grouped implementation, whole-grid
+ * contexts with fluid_size.x % 4 == 0:
+ *   (FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES, 2)   VELOCITIES_2 is left unspecified (07 rewrites it)
+ *   (FLUID_SEC_07_ADVECT, 2)                            exact
+ *   (FLUID_SEC_09_DIFFUSE, 3)                           exact (FLUID_DIFFUSE_REFERENCE_EXACT)
+ * Any other slice, or a grouped one whose precondition does not hold, runs section by section.
+ * fluid_run_step uses these groups unless FLUID_OPT_STEP_FUSION = 1.  Not available on Z-slab
+ * contexts (the caller exchanges ghost planes between sections there). */
+int fluid_run_section_group(fluid_ctx* ctx, int first_section_id, uint32_t count);
+
 /* FlowClearColorSection(ctx, image, ClearValue) for an arbitrary image and value
  * (fluid_flow_sections.h:140-142,163,298-299 are the uses on this path).  `value_bits` holds the
  * texel as 32-bit patterns: 4 words for RGBA32F, 1 for R32F / R32_UINT, the low byte of word 0 for
@@ -344,6 +358,10 @@ typedef enum fluid_option {
                                    /* buffer fast path with 1/2/4/1 rows per wavefront               */
     FLUID_OPT_JACOBI_FUSE = 1,     /* loop section: 0 = two sweeps per pass over HBM (default),     */
                                    /* 1 = one kernel launch per sweep                               */
+    FLUID_OPT_STEP_FUSION = 2,     /* fluid_run_step: 0 = sections 04+05, 07+08 and 09+10+11 run as   */
+                                   /* grouped passes (default; every image ends the step with the   */
+                                   /* bits the section list leaves, intermediates are not stored),  */
+                                   /* 1 = the section list, one kernel per section                  */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

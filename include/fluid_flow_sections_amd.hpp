@@ -138,6 +138,9 @@ public:
     virtual ~FlowSection() = default;
     virtual void run(FlowDescriptorContext& ctx) = 0;
     virtual std::string name() const = 0;
+    // fluid_section_id of a plain compute section (one dispatch, no push constant), else -1: lets a
+    // list hand runs of consecutive sections to fluid_run_section_group
+    virtual int computeSectionId() const { return -1; }
 };
 
 // FlowClearColorSection(ctx, image, clear value) — fluid_flow_sections.h:140-142,163,298-299
@@ -179,6 +182,7 @@ public:
         ctx.check(fluid_run_section(ctx.handle(), m_section));
     }
     std::string name() const override { return m_name; }
+    int computeSectionId() const override { return m_section; }
 
 protected:
     std::string m_name;
@@ -196,6 +200,7 @@ public:
     }
     using FlowComputeSection::run;
     int section() const { return m_section; }
+    int computeSectionId() const override { return -1; }
 };
 
 // FlowLoopPushConstantSection<FlowComputePushConstantSection>(iterations, …) — :300-313
@@ -229,11 +234,31 @@ public:
     void complete() { m_completed = true; }
     // reference: run(CommandBuffer&, FlowDescriptorContext&) records into a command buffer that
     // is submitted afterwards (main.cpp:111-122,170-176); here sections enqueue directly on the
-    // context's stream, in list order
+    // context's stream, in list order.  A run of compute sections that are consecutive entries of
+    // the reference's step list goes to the engine as one slice (fluid_run_section_group), which lets
+    // it execute 04+05, 07+08 and 09+10+11 as single passes; results are the list's.
     void run(FlowDescriptorContext& ctx) {
         if (!m_completed) throw FluidError(FLUID_ERR_INVALID_ARG, "complete() the list first");
-        for (auto& s : m_sections) s->run(ctx);
+        const size_t n = m_sections.size();
+        for (size_t i = 0; i < n;) {
+            const int id = m_sections[i]->computeSectionId();
+            size_t j = i + 1;
+            if (m_group_slices && id >= FLUID_SEC_01_UPDATE_DENSITIES && id <= FLUID_SEC_14_PARTICLES &&
+                id != FLUID_SEC_12_SOLVE_PRESSURE)
+                while (j < n && m_sections[j]->computeSectionId() == id + (int)(j - i) &&
+                       id + (int)(j - i) != FLUID_SEC_12_SOLVE_PRESSURE)
+                    j++;
+            if (j - i >= 2) {
+                ctx.check(fluid_run_section_group(ctx.handle(), id, (uint32_t)(j - i)));
+            } else {
+                m_sections[i]->run(ctx);
+                j = i + 1;
+            }
+            i = j;
+        }
     }
+    // false: one engine call per list entry, nothing grouped
+    void setGroupSlices(bool on) { m_group_slices = on; }
     void run() { run(*m_ctx); }
     size_t size() const { return m_sections.size(); }
     const FlowSection& operator[](size_t i) const { return *m_sections[i]; }
@@ -242,6 +267,7 @@ private:
     FlowDescriptorContext* m_ctx;
     std::vector<std::unique_ptr<FlowSection>> m_sections;
     bool m_completed = false;
+    bool m_group_slices = true;
 };
 
 // fluid_flow_sections.h:136-156 (minus the inertia clear :142, surface path)

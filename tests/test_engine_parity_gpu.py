@@ -47,6 +47,63 @@ def test_section_matches_oracle(section, size):
         assert_state_equal(eng, st, ctx=f"{section} {size}: ")
 
 
+STEP_LIST = list(OracleState.STEP_BEFORE_12)
+# (first section, count, images the group may leave unspecified, a section whose own kernel must not run)
+GROUPS = [("04_compute_extrapolated_velocities", 2, ["velocities_2"], None),
+          ("07_advect", 2, [], "08_forces"),
+          ("09_diffuse", 3, [], "10_solids"),
+          ("02_update_water", 10, ["velocities_2"], "08_forces")]
+
+
+@pytest.mark.parametrize("size", [(24, 20, 16), (64, 8, 5), (260, 6, 4), (8, 5, 5), (17, 13, 9)])
+@pytest.mark.parametrize("group", GROUPS, ids=[g[0] + "x" + str(g[1]) for g in GROUPS])
+def test_section_group_matches_oracle(group, size):
+    """fluid_run_section_group: grouped passes (kernels_step_fused.h) against the oracle running the
+    same sections one by one, on scenes with every cell type anywhere (interior solids included)."""
+    first, count, unspecified, skipped = group
+    st = random_state(size, capacity=200, seed=zlib.crc32(repr((first, size)).encode()) % 1000)
+    with make_engine(st) as eng:
+        # 13 leaves w = 0 in all of VELOCITIES_1, the precondition of the grouped 04+05
+        eng.run_section("13_fix_divergence")
+        st.run_section("13_fix_divergence")
+        eng.enable_timing(True)
+        eng.run_section_group(first, count)
+        i = STEP_LIST.index(first)
+        for s in STEP_LIST[i:i + count]:
+            st.run_section(s)
+        fields = [f for f in list(IMAGE_FIELDS) + ["particles"] if f not in unspecified]
+        if count == 10:  # ... through 11: VELOCITIES_2 is rewritten by 07 (+08), so it is exact again
+            fields = list(IMAGE_FIELDS) + ["particles"]
+        assert_state_equal(eng, st, fields=fields, ctx=f"group {first}x{count} {size}: ")
+        if skipped and size[0] % 4 == 0:
+            assert eng.section_times()[skipped][1] == 0  # the grouped pass ran, not the list
+
+
+def test_section_group_errors():
+    st = random_state((8, 8, 8), seed=3)
+    with make_engine(st) as eng:
+        for first, count in [(E.SECTION_IDS["00_init_particles"], 1), (E.SECTION_IDS["14_particles"], 2),
+                             (99, 1)]:
+            with pytest.raises(fluid_amd.FluidEngineError, match="not a slice"):
+                eng.run_section_group(first, count)
+        eng.run_section_group("14_particles", 0)  # empty slice: nothing to do
+
+
+@pytest.mark.parametrize("size", [(24, 20, 16), (32, 12, 40)])
+def test_full_step_grouped_equals_list_and_oracle(size):
+    """fluid_run_step with and without FLUID_OPT_STEP_FUSION from an arbitrary uploaded state: the
+    first step runs 04/05 from the list (w of VELOCITIES_1 unknown after an upload), later ones grouped."""
+    st = random_state(size, capacity=4000, seed=5, iters=6)
+    with make_engine(st) as a, make_engine(st) as b:
+        b.set_option(E.OPT_STEP_FUSION, 1)
+        for k in range(3):
+            a.run_step()
+            b.run_step()
+            st.run_step()
+            assert_state_equal(a, st, ctx=f"grouped, step {k}: ")
+            assert_state_equal(b, st, ctx=f"list, step {k}: ")
+
+
 @pytest.mark.parametrize("size", [(24, 20, 16), (17, 13, 9)])
 def test_diffuse_intended_mode(size):
     st = random_state(size, seed=11)

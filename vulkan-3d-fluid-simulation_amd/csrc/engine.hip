@@ -19,6 +19,7 @@
 #include "kernels_grid.h"
 #include "pressure_api.h"
 #include "kernels_sampler.h"
+#include "kernels_step_fused.h"
 
 static_assert(sizeof(fluid_params) == FLUID_PARAMS_BYTES, "params block must be 264 bytes");
 static_assert(offsetof(fluid_params, particle_compute_size) == 48, "std140 offset");
@@ -87,6 +88,7 @@ struct fluid_ctx {
                                           // [2] bricks holding water
     uint32_t* brick_count_host = nullptr; // pinned, 5 words (k12_count_bricks); written by an async
                                           // copy after k12_prepare
+    bool v1_w_zero = false;               // every texel of VELOCITIES_1 has w == +0.0f (kernels_step_fused.h)
     bool box_pending = false;             // that copy has been enqueued and not been waited for
     ActiveBox box;                        // where the water is, for launch shaping
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
@@ -143,6 +145,8 @@ struct fluid_ctx {
             bg_valid[0] = bg_valid[1] = bg_valid[2] = false;
         } else if (image == FLUID_IMG_DIVERGENCES) {
             rhs_valid = false;
+        } else if (image == FLUID_IMG_VELOCITIES_1) {
+            v1_w_zero = false;
         }
     }
     uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
@@ -606,6 +610,14 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
                    what);
 }
 
+// internal ids of the grouped passes, past the public section ids
+enum : int {
+    STEP_0405_EXTRAPOLATE = FLUID_SECTION_COUNT + 1,
+    STEP_0405_APPLY,
+    STEP_0708_ADVECT_FORCES,
+    STEP_091011_SOLIDS_DIVERGENCE,
+};
+
 // ---- one section --------------------------------------------------------------------------------
 int run_section_impl(fluid_ctx* c, int section) {
     const GridK& g = c->g;
@@ -620,6 +632,7 @@ int run_section_impl(fluid_ctx* c, int section) {
 
     switch (section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
+            c->v1_w_zero = true;
             return fill_image(c, FLUID_IMG_VELOCITIES_1, 0u);
         case FLUID_SEC_INIT_CLEAR_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
@@ -659,6 +672,25 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES:
             hipLaunchKernelGGL(k05_set_extrapolated, grid, block, 0, c->stream, newT, T, V2, V1, g,
                                pk);
+            c->v1_w_zero = true;
+            break;
+        // grouped passes of fluid_run_step (kernels_step_fused.h); not part of the public section ids
+        case STEP_0405_EXTRAPOLATE:
+            hipLaunchKernelGGL(k0405_extrapolate, cell4_grid(g), block, 0, c->stream, T, newT, V1, V2,
+                               g, pk);
+            break;
+        case STEP_0405_APPLY:
+            hipLaunchKernelGGL(k0405_apply, cell4_grid(g), block, 0, c->stream, T, newT, V2, V1, g, pk);
+            break;
+        case STEP_0708_ADVECT_FORCES:
+            hipLaunchKernelGGL(k07_advect<true>, grid, block, 0, c->stream, T, V1, V2, g, pk,
+                               c->flags());
+            break;
+        case STEP_091011_SOLIDS_DIVERGENCE:
+            c->touched(FLUID_IMG_DIVERGENCES);
+            c->v1_w_zero = false;
+            hipLaunchKernelGGL(k091011_solids_divergence, grid, block, 0, c->stream, T, V2, V1,
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
@@ -668,7 +700,8 @@ int run_section_impl(fluid_ctx* c, int section) {
                                       hipMemcpyDeviceToDevice, c->stream));
             return FLUID_OK;
         case FLUID_SEC_07_ADVECT:
-            hipLaunchKernelGGL(k07_advect, grid, block, 0, c->stream, T, V1, V2, g, pk, c->flags());
+            hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
+                               c->flags());
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
@@ -680,9 +713,11 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k09_diffuse<true>, grid, block, 0, c->stream, T, V2, V1, g, pk);
             else
                 hipLaunchKernelGGL(k09_diffuse<false>, grid, block, 0, c->stream, T, V2, V1, g, pk);
+            c->v1_w_zero = true;
             break;
         case FLUID_SEC_10_SOLIDS:
             hipLaunchKernelGGL(k10_solids, grid, block, 0, c->stream, T, V1, g, pk);
+            c->v1_w_zero = false;
             break;
         case FLUID_SEC_11_COMPUTE_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
@@ -703,6 +738,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_13_FIX_DIVERGENCE:
             hipLaunchKernelGGL(k13_fix_divergence, grid, block, 0, c->stream, T,
                                c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk);
+            c->v1_w_zero = true;
             break;
         case FLUID_SEC_14_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
@@ -716,13 +752,14 @@ int run_section_impl(fluid_ctx* c, int section) {
     return FLUID_OK;
 }
 
-int timed_section(fluid_ctx* c, int section) {
+// `impl` (a grouped pass of fluid_run_step) runs in place of `section` and is timed under its id
+int timed_section(fluid_ctx* c, int section, int impl = -1) {
     if (section < 0 || section >= FLUID_SECTION_COUNT)
         return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section);
     SectionTimer tm{c};
     int rc = tm.begin(section);
     if (rc) return rc;
-    rc = run_section_impl(c, section);
+    rc = run_section_impl(c, impl >= 0 ? impl : section);
     int rc2 = tm.end();
     return rc ? rc : rc2;
 }
@@ -1239,27 +1276,58 @@ int fluid_run_init(fluid_ctx* c) {
     return FLUID_OK;
 }
 
+// Entries [first, first + count) of SimulationStepSections (fluid_flow_sections.h:163-338; the ids are
+// consecutive in list order).  `grouped`: sections 04+05, 07+08 and 09+10+11 run as the grouped passes
+// of kernels_step_fused.h, each timed under the id of the section it stands in for.
+static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped) {
+    const bool group = grouped && c->g.W % 4 == 0;
+    const int end = first + count;
+    for (int s = first; s < end;) {
+        int rc, used = 1;
+        if (group && s == FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES && end - s >= 2 &&
+            c->v1_w_zero) {  // the pair of type scans needs w == 0 in all of VELOCITIES_1
+            rc = timed_section(c, s, STEP_0405_EXTRAPOLATE);
+            if (rc == FLUID_OK)
+                rc = timed_section(c, FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES, STEP_0405_APPLY);
+            used = 2;
+        } else if (group && s == FLUID_SEC_07_ADVECT && end - s >= 2) {
+            rc = timed_section(c, s, STEP_0708_ADVECT_FORCES);
+            used = 2;
+        } else if (group && s == FLUID_SEC_09_DIFFUSE && end - s >= 3 &&
+                   c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT) {
+            rc = timed_section(c, s, STEP_091011_SOLIDS_DIVERGENCE);
+            used = 3;
+        } else if (s == FLUID_SEC_12_SOLVE_PRESSURE) {
+            rc = fluid_run_section_loop(c, s, c->pressure_iterations);
+        } else {
+            rc = timed_section(c, s);
+        }
+        if (rc) return rc;
+        s += used;
+    }
+    return FLUID_OK;
+}
+
 int fluid_run_step(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    // fluid_flow_sections.h:163-338, list order
-    static const int before[] = {
-        FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES, FLUID_SEC_01_UPDATE_DENSITIES,
-        FLUID_SEC_02_UPDATE_WATER, FLUID_SEC_03_UPDATE_AIR,
-        FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES, FLUID_SEC_05_SET_EXTRAPOLATED_VELOCITIES,
-        FLUID_SEC_06_UPDATE_CELL_TYPES, FLUID_SEC_07_ADVECT, FLUID_SEC_08_FORCES,
-        FLUID_SEC_09_DIFFUSE, FLUID_SEC_10_SOLIDS, FLUID_SEC_11_COMPUTE_DIVERGENCE,
-        FLUID_SEC_12A_CLEAR_PRESSURES_1, FLUID_SEC_12B_CLEAR_PRESSURES_2};
     if (c->is_slab) return slab_unsupported(c, "fluid_run_step");
-    for (int s : before) {
-        int rc = timed_section(c, s);
-        if (rc) return rc;
-    }
-    int rc = fluid_run_section_loop(c, FLUID_SEC_12_SOLVE_PRESSURE, c->pressure_iterations);
-    if (rc) return rc;
-    rc = timed_section(c, FLUID_SEC_13_FIX_DIVERGENCE);
-    if (rc) return rc;
-    return timed_section(c, FLUID_SEC_14_PARTICLES);
+    return run_step_slice(c, FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES,
+                          FLUID_SEC_14_PARTICLES - FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES + 1,
+                          c->opt[FLUID_OPT_STEP_FUSION] == 0);
+}
+
+int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (first_section_id < FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES ||
+        first_section_id > FLUID_SEC_14_PARTICLES ||
+        count > (uint32_t)(FLUID_SEC_14_PARTICLES - first_section_id + 1))
+        return c->fail(FLUID_ERR_INVALID_ARG,
+                       "sections [%d, %d + %u) are not a slice of the step section list",
+                       first_section_id, first_section_id, count);
+    if (c->is_slab) return slab_unsupported(c, "fluid_run_section_group");
+    return run_step_slice(c, first_section_id, (int)count, true);
 }
 
 int fluid_sync(fluid_ctx* c) {

@@ -87,7 +87,9 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
     return keep;  // :79
 }
 
-// 07_advect/advect.comp:84-97
+// 07_advect/advect.comp:84-97.  FORCES: 08_forces/forces.comp:33-54 applied to the value before it is
+// stored (fluid_run_step; 08 is a pointwise update of VELOCITIES_2, see kernels_step_fused.h).
+template <bool FORCES>
 __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                            float4* __restrict__ v2, GridK g, ParamsK p,
                            uint32_t* __restrict__ violation) {
@@ -104,6 +106,21 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
     o.y = advect_component<1>(t, v1, g, p, x, y, lz, gz, cur_water, cur.y, violation);
     o.z = advect_component<2>(t, v1, g, p, x, y, lz, gz, cur_water, cur.z, violation);
     o.w = 0.0f;
+    if (FORCES) {
+        const uint32_t t2 = type_at(t, g, x, y - 1, lz);
+        const bool wet = cur_water || (t2 == p.t_water);
+        float fy = 0.0f;
+        if (y != 0 && wet) fy += p.gravity;  // forces.comp:39-45
+        if ((uint32_t)x == p.fountain[0] && (uint32_t)y == p.fountain[1] &&
+            (uint32_t)gz == p.fountain[2] && wet)
+            fy += p.fountain_force;  // :47-49
+        if (fy != 0.0f) {            // :52-53
+            o.x = o.x + p.dt * 0.0f;
+            o.y = o.y + p.dt * fy;
+            o.z = o.z + p.dt * 0.0f;
+            o.w = o.w + 0.0f;
+        }
+    }
     v2[id] = o;  // :96
 }
 

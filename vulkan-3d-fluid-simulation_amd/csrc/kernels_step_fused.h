@@ -1,0 +1,182 @@
+// kernels_step_fused.h — section groups of one whole step (fluid_run_step) executed as single passes.
+//
+// The section list of the reference (fluid_flow_sections.h:163-338) moves the RGBA32F velocity images
+// through HBM nine times per step.  Run as a list, each section is its own kernel (kernels_grid.h,
+// kernels_sampler.h) and that is what fluid_run_section() does.  fluid_run_step() knows the whole
+// list, so it may group sections whose intermediate images nobody can observe, as long as every image
+// holds, when the step ends, exactly the bits the list would have left:
+//
+//   04 + 05   04 writes the extrapolated velocity of EVERY cell to VELOCITIES_2, 05 consumes it only in
+//             the cells whose activity changed, and 07 then overwrites all of VELOCITIES_2.  Here the
+//             extrapolation is evaluated only where 05 will use it (k0405_extrapolate), and 05 touches
+//             VELOCITIES_1 only where a component changes (k0405_apply): two scans of the 1-byte type
+//             images instead of four passes over 16-byte velocities.  Requires VELOCITIES_1.w == 0
+//             everywhere on entry (true after 13_fix_divergence / the init clear; tracked by the engine),
+//             because 05 also stores w = 0.
+//   07 + 08   forces are a pointwise update of what advection just produced (k07_advect<true>).
+//   09 + 10 + 11   09 (as written: a copy) and 10 are pointwise, 11 differences the result with its
+//             +x/+y/+z neighbours: one pass reads VELOCITIES_2, applies 10 to the cell and to the three
+//             neighbour components it needs, writes VELOCITIES_1 and DIVERGENCES.
+//
+// Arithmetic is the per-section kernels' (same operations, same order): results are bit-identical,
+// which tests/test_engine_parity_gpu.py checks against the oracle and against the section list.
+// Whole-grid contexts only (a Z slab exchanges ghost planes between these sections).
+#pragma once
+
+#include "device_common.h"
+
+namespace fluid {
+
+// ---- 04 + 05 ------------------------------------------------------------------------------------------
+// Per-component state of 05 (extrapolate_velocities.comp:48-56) for the four cells x..x+3 of a row:
+// bits [2c, 2c+1] of byte i = component c of cell i: 1 = VELOCITY_RESET, 2 = VELOCITY_EXTRAPOLATE.
+__device__ __forceinline__ uint32_t activity_states4(const uint8_t* __restrict__ oldT,
+                                                     const uint8_t* __restrict__ newT, const GridK& g,
+                                                     const ParamsK& p, int x, int y, int lz,
+                                                     int64_t id) {
+    auto act = [&](uint32_t a) { return a == p.t_water || a == p.t_air; };  // :34-36
+    auto word = [&](const uint8_t* t, int64_t at) { return *reinterpret_cast<const uint32_t*>(t + at); };
+    const uint32_t o_c = word(oldT, id), n_c = word(newT, id);
+    // -y neighbours: out of bounds reads as type 0 (device_common.h: type_at); -z: ghost planes
+    const uint32_t o_y = y > 0 ? word(oldT, id - g.W) : 0u, n_y = y > 0 ? word(newT, id - g.W) : 0u;
+    const uint32_t o_z = word(oldT, id - g.plane), n_z = word(newT, id - g.plane);
+    const uint32_t o_l = x > 0 ? (uint32_t)oldT[id - 1] : 0u, n_l = x > 0 ? (uint32_t)newT[id - 1] : 0u;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int sh = 8 * i;
+        const bool was = act((o_c >> sh) & 0xFFu), is = act((n_c >> sh) & 0xFFu);  // :88-90
+        const uint32_t ox = i == 0 ? o_l : (o_c >> (sh - 8 * (i > 0))) & 0xFFu;
+        const uint32_t nx = i == 0 ? n_l : (n_c >> (sh - 8 * (i > 0))) & 0xFFu;
+        const uint32_t onb[3] = {ox, (o_y >> sh) & 0xFFu, (o_z >> sh) & 0xFFu};
+        const uint32_t nnb[3] = {nx, (n_y >> sh) & 0xFFu, (n_z >> sh) & 0xFFu};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool vwas = was || act(onb[c]);  // :50
+            const bool vis = is || act(nnb[c]);    // :52
+            const uint32_t st = (vwas && !vis) ? 1u : ((!vwas && vis) ? 2u : 0u);
+            out |= st << (sh + 2 * c);
+        }
+    }
+    return out;
+}
+constexpr uint32_t STATE_ANY_EXTRAPOLATE = 0x2Au;  // bits of the three "2" states in a byte
+
+#define FLUID_CELL4_ROW_THREAD()                                    \
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);      \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;            \
+    const int lz = blockIdx.z;                                      \
+    if (x >= g.W || y >= g.H) return;                               \
+    const int64_t id = cidx(g, x, y, lz);                           \
+    const int gz = g.z0 + lz;
+
+// 04 where 05 needs it: VELOCITIES_2[cell] = mean velocity of the cell's WATER neighbours
+// (extrapolated_velocities.comp:37-63) for cells with a component in state VELOCITY_EXTRAPOLATE.
+__global__ void k0405_extrapolate(const uint8_t* __restrict__ oldT, const uint8_t* __restrict__ newT,
+                                  const float4* __restrict__ v1, float4* __restrict__ v2, GridK g,
+                                  ParamsK p) {
+    FLUID_CELL4_ROW_THREAD();
+    const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);
+    if ((st & (STATE_ANY_EXTRAPOLATE * 0x01010101u)) == 0u) return;
+    for (int i = 0; i < 4; i++) {
+        if (((st >> (8 * i)) & STATE_ANY_EXTRAPOLATE) == 0u) continue;
+        const int xi = x + i;
+        int n = 0;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#define FLUID_ACC(cond, nx, ny, nlz)                                         \
+    if ((cond) && (uint32_t)oldT[cidx(g, nx, ny, nlz)] == p.t_water) {       \
+        const float4 q = v1[cidx(g, nx, ny, nlz)];                           \
+        sx = sx + q.x;                                                       \
+        sy = sy + q.y;                                                       \
+        sz = sz + q.z;                                                       \
+        n++;                                                                 \
+    }
+        FLUID_ACC(xi != 0, xi - 1, y, lz)         // :46
+        FLUID_ACC(y != 0, xi, y - 1, lz)          // :47
+        FLUID_ACC(gz != 0, xi, y, lz - 1)         // :48
+        FLUID_ACC(xi != g.W - 1, xi + 1, y, lz)   // :49
+        FLUID_ACC(y != g.H - 1, xi, y + 1, lz)    // :50
+        FLUID_ACC(gz != g.Dg - 1, xi, y, lz + 1)  // :51
+#undef FLUID_ACC
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n != 0) {  // :53
+            const float fc = (float)n;
+            o.x = sx / fc;
+            o.y = sy / fc;
+            o.z = sz / fc;
+        }
+        v2[id + i] = o;  // :62
+    }
+}
+
+// 05 where it changes anything (extrapolate_velocities.comp:88-108); cells without a RESET /
+// EXTRAPOLATE component keep their bits (w is 0 already, see the header comment).
+__global__ void k0405_apply(const uint8_t* __restrict__ oldT, const uint8_t* __restrict__ newT,
+                            const float4* __restrict__ v2, float4* __restrict__ v1, GridK g,
+                            ParamsK p) {
+    FLUID_CELL4_ROW_THREAD();
+    (void)gz;
+    const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);
+    if (st == 0u) return;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s = (st >> (8 * i)) & 0x3Fu;
+        if (s == 0u) continue;
+        const float4 base = v1[id + i];  // :93
+        float4 ext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s & STATE_ANY_EXTRAPOLATE) ext = v2[id + i];  // :95
+        float cur[3] = {base.x, base.y, base.z};
+        const float ex[3] = {ext.x, ext.y, ext.z};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t sc = (s >> (2 * c)) & 3u;
+            if (sc == 1u)
+                cur[c] = 0.0f;  // VELOCITY_RESET
+            else if (sc == 2u)
+                cur[c] = ex[c];  // VELOCITY_EXTRAPOLATE
+        }
+        v1[id + i] = make_float4(cur[0], cur[1], cur[2], 0.0f);  // :108
+    }
+}
+
+// ---- 09 (as written) + 10 + 11 -------------------------------------------------------------------------
+// one component through 10_solids (solids.comp:32-36 then :50-51)
+__device__ __forceinline__ float solids_component(float v, bool cell_solid, bool lower_solid, float r) {
+    if (cell_solid && v > -r) v = -r;
+    if (lower_solid && v < r) v = r;
+    return v;
+}
+
+__global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
+                                          const float4* __restrict__ v2, float4* __restrict__ v1,
+                                          float* __restrict__ div, GridK g, ParamsK p) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    const float r = p.repel;
+    const float4 q = v2[id];  // diffuse.comp:34,46: the copy
+    const bool solid = (uint32_t)t[id] == p.t_solid;
+    const float vx = solids_component(q.x, solid, type_at(t, g, x - 1, y, lz) == p.t_solid, r);
+    const float vy = solids_component(q.y, solid, type_at(t, g, x, y - 1, lz) == p.t_solid, r);
+    const float vz = solids_component(q.z, solid, (uint32_t)t[id - g.plane] == p.t_solid, r);
+    v1[id] = make_float4(vx, vy, vz, 1.0f);  // solids.comp:76
+    // compute_divergence.comp:18-30 on the field 10 produces: the +x/+y/+z neighbours' components go
+    // through 10 here as well (their lower neighbour along that axis is this cell); outside the grid the
+    // image load returns 0
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (x + 1 < g.W)
+        ax = solids_component(v2[id + 1].x, (uint32_t)t[id + 1] == p.t_solid, solid, r);
+    if (y + 1 < g.H)
+        ay = solids_component(v2[id + g.W].y, (uint32_t)t[id + g.W] == p.t_solid, solid, r);
+    if (lz + 1 < g.Dl)
+        az = solids_component(v2[id + g.plane].z, (uint32_t)t[id + g.plane] == p.t_solid, solid, r);
+    float d = ax - vx;  // :21 left to right
+    d = d + ay;
+    d = d - vy;
+    d = d + az;
+    d = d - vz;
+    div[id] = d;
+}
+
+}  // namespace fluid

@@ -47,6 +47,7 @@ SECTION_COUNT = len(SECTION_NAMES)
 DIFFUSE_REFERENCE_EXACT, DIFFUSE_INTENDED = 0, 1
 OPT_PRESSURE_KERNEL = 0
 OPT_JACOBI_FUSE = 1
+OPT_STEP_FUSION = 2
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
     0, -1, -2, -3, -4, -5, -6)
@@ -57,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "fluid_destroy", "fluid_last_error", "fluid_upload_image", "fluid_download_image",
     "fluid_upload_buffer", "fluid_download_buffer", "fluid_image_bytes", "fluid_buffer_bytes",
     "fluid_set_params", "fluid_set_pressure_iterations", "fluid_set_diffuse_mode",
-    "fluid_run_section", "fluid_run_section_loop", "fluid_clear_image",
+    "fluid_run_section", "fluid_run_section_loop", "fluid_run_section_group", "fluid_clear_image",
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
@@ -123,6 +124,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_set_diffuse_mode": (C.c_int, [vp, C.c_int]),
         "fluid_run_section": (C.c_int, [vp, C.c_int]),
         "fluid_run_section_loop": (C.c_int, [vp, C.c_int, u32]),
+        "fluid_run_section_group": (C.c_int, [vp, C.c_int, u32]),
         "fluid_clear_image": (C.c_int, [vp, C.c_int, C.POINTER(u32 * 4)]),
         "fluid_run_pressure_dispatch": (C.c_int, [vp, u32]),
         "fluid_run_init": (C.c_int, [vp]),
@@ -292,6 +294,11 @@ class FluidEngine:
     def run_section_loop(self, section, iterations: int):
         sid = SECTION_IDS[section] if isinstance(section, str) else int(section)
         self._check(self._lib.fluid_run_section_loop(self._h, sid, iterations))
+
+    def run_section_group(self, first_section, count: int):
+        """`count` consecutive step sections as one unit (include/fluid_engine.h)."""
+        sid = SECTION_IDS[first_section] if isinstance(first_section, str) else int(first_section)
+        self._check(self._lib.fluid_run_section_group(self._h, sid, count))
 
     def solve_pressure(self, iterations: int):
         """The 12_solve_pressure loop section (fluid_flow_sections.h:300-313)."""
