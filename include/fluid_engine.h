@@ -316,6 +316,25 @@ int fluid_pressure_loop_advance(fluid_ctx* ctx, uint32_t sweeps, int keep_interm
                                 int* written_buffer);
 int fluid_pressure_loop_halo_exchanged(fluid_ctx* ctx, uint32_t depth, uint32_t aux_depth);
 int fluid_pressure_loop_end(fluid_ctx* ctx);
+/* A two-sweep pass as two launches, so that a halo exchange can run beside the larger one:
+ *   FLUID_LOOP_PART_INTERIOR  writes the output planes [interior_begin, interior_end) (local plane
+ *                             numbers, clipped to the planes the pass writes)
+ *   FLUID_LOOP_PART_EDGES     writes the rest, below and above, in one launch
+ * in either order with the same arguments; the second call completes the pass (state as after
+ * fluid_pressure_loop_advance(ctx, 2, keep_intermediate, …)); *written_buffer is the destination
+ * buffer after either call.  The schedule this is for, with h ghost planes exchanged every h sweeps:
+ *   last pass before an exchange:  EDGES with interior [h, z_count - h) first — the h planes per face
+ *       to send are complete when it ends —, start the exchange on another stream, then INTERIOR;
+ *   first pass after it:  call fluid_pressure_loop_halo_exchanged when the exchange is STARTED, launch
+ *       INTERIOR with [2, z_count - 2) (its inputs are owned planes only), make this context's stream
+ *       wait for the receives, then EDGES.
+ * At a domain face there is no edge: pass the plane range's natural end there (e.g. INT32_MIN /
+ * INT32_MAX; the engine clips). */
+#define FLUID_LOOP_PART_EDGES 1
+#define FLUID_LOOP_PART_INTERIOR 2
+int fluid_pressure_loop_advance_part(fluid_ctx* ctx, int keep_intermediate, int part,
+                                     int32_t interior_begin, int32_t interior_end,
+                                     int* written_buffer);
 int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes);
 

@@ -545,3 +545,33 @@ def test_pressure_fused_sparse_scene_and_bricks():
         eng.solve_pressure(10)
         st.solve_pressure(10)
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="sparse fused: ")
+
+
+@pytest.mark.parametrize("size", [(64, 24, 40), (512, 9, 21)])
+def test_pressure_split_passes_equal_whole_passes(size):
+    """fluid_pressure_loop_advance_part: a pass as EDGES + INTERIOR launches, in either order, equals
+    the whole pass (and the oracle); misuse is reported."""
+    st = random_state(size, seed=9, iters=8)
+    d = size[2]
+    with make_engine(st) as eng:
+        eng.pressure_loop_begin()
+        edges, interior = eng.LOOP_PART_EDGES, eng.LOOP_PART_INTERIOR
+        # pass 1: edges first; pass 2: interior first; pass 3: interior covers everything; pass 4:
+        # empty interior, keeps the odd iterate (last pair of an 8-sweep loop)
+        plans = [(False, edges, 5, d - 5), (False, interior, 2, d - 2),
+                 (False, interior, -2 ** 31, 2 ** 31 - 1), (True, edges, 7, 7)]
+        for keep, first, lo, hi in plans:
+            other = interior if first == edges else edges
+            w1 = eng.pressure_loop_advance_part(keep, first, lo, hi)
+            with pytest.raises(fluid_amd.FluidEngineError, match="other part"):
+                eng.pressure_loop_advance_part(keep, first, lo, hi)       # same part twice
+            with pytest.raises(fluid_amd.FluidEngineError, match="other part"):
+                eng.pressure_loop_advance_part(not keep, other, lo, hi)  # other arguments
+            with pytest.raises(fluid_amd.FluidEngineError, match="half done"):
+                eng.pressure_loop_advance(2, keep)
+            with pytest.raises(fluid_amd.FluidEngineError, match="half done"):
+                eng.pressure_loop_end()
+            assert eng.pressure_loop_advance_part(keep, other, lo, hi) == w1
+        eng.pressure_loop_end()
+        st.solve_pressure(8)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="split passes: ")

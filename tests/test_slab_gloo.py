@@ -83,6 +83,11 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
     comp.upload(E.PRESSURES_2, st.pressures_2[z0:z0 + n])
     solver.solve(iters + 1)
     b1, b2 = solver.gather_pressures()
+    thinnest = min(m for _, m in partition_z(d, world))
+    if max_sweeps >= 2 and solver.effective_halo() >= 4 and thinnest > 2 * solver.effective_halo():
+        assert solver.overlapped > 0  # the split-pass schedule ran
+    else:
+        assert solver.overlapped == 0
     if rank == 0:
         np.savez(os.path.join(out_dir, "result.npz"), a1=a1, a2=a2, b1=b1, b2=b2)
     dist.barrier()
@@ -95,6 +100,9 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
     (3, (8, 9, 11), 5, 2, 8),      # slabs of 4/4/3 planes clip the halo to 2
     (3, (8, 9, 20), 9, 2, 4),      # 7/7/6 planes, halo 4
     (2, (10, 8, 9), 4, 1, 8),      # one sweep per launch: one plane per sweep
+    (2, (12, 10, 20), 13, 2, 4),   # slabs of 10 planes, halo 4: exchanges overlap split passes
+    (3, (8, 9, 30), 18, 2, 4),     # three ranks (the middle one has two neighbours), overlapped
+    (2, (8, 8, 40), 20, 2, 8),     # halo 8 on slabs of 20 planes, overlapped
 ])
 def test_slab_solver_equals_single_domain_oracle(world, size, iters, max_sweeps, halo, tmp_path):
     import torch.multiprocessing as mp

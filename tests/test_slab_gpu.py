@@ -70,6 +70,9 @@ def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir):
     (3, (256, 12, 13), 8, 7, 4),    # explicit fast-path kernel option
     (2, (64, 24, 20), 7, 2, 8),     # general kernel on the images: one plane per sweep
     (2, (17, 9, 8), 4, 0, 8),       # width not a multiple of 4: falls back to the images as well
+    (2, (64, 24, 40), 21, 0, 8),    # slabs of 20 planes, halo 8: split passes around the exchanges
+    (3, (256, 12, 30), 14, 0, 4),   # three ranks, halo 4 on slabs of 10 planes, split passes
+    (2, (512, 7, 24), 12, 0, 4),    # two x tiles per row
 ])
 def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, tmp_path):
     import torch.multiprocessing as mp

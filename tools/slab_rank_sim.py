@@ -50,7 +50,8 @@ for ranks in a.ranks:
         gpu_ms, calls = comp.engine.section_time_ms("12_solve_pressure")
         comp.engine.enable_timing(False)
         print(f"   kernel time {gpu_ms / reps / a.iters:.4f} ms/sweep ({calls // reps} sweeps counted)")
-        print(f"ranks {ranks} (slab {slab[1]} planes) halo {solver.effective_halo()}: "
+        print(f"ranks {ranks} (slab {slab[1]} planes) halo {solver.effective_halo()} "
+              f"overlapped {solver.overlapped // (reps + 1)}: "
               f"{1e3 * dt / a.iters:.4f} ms/sweep -> {a.iters / dt:9.1f} iterations/s, "
               f"{solver.exchanges // reps} exchanges per {a.iters} sweeps")
     comp.close()

@@ -105,6 +105,9 @@ struct fluid_ctx {
                              // every sweep, restored by the caller's halo exchange)
     int loop_aux_halo = 0;   // ... of mask / b_i (fixed for the loop)
     bool loop_ghost_bg = false;  // ghost planes of the other two buffers hold their constants
+    int loop_part_done = 0;      // FUSED_EDGES / FUSED_INTERIOR: that half of a split pass is launched
+    bool loop_part_keep = false;
+    int loop_part_lo = 0, loop_part_hi = 0;
 
     bool timing = false;
     std::vector<TimerSlot> pending;
@@ -508,13 +511,14 @@ int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1)
 
 // two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
 // j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
-int launch_fused(fluid_ctx* c, int src, int dst, int mid) {
+int launch_fused(fluid_ctx* c, int src, int dst, int mid, int part = FUSED_WHOLE, int part_lo = 0,
+                 int part_hi = 0) {
     const bool lo = c->g.z0 > 0, hi = c->g.z0 + c->g.Dl < c->g.Dg;  // neighbouring slabs
     HIP_TRY(c, k12_launch_canon2(c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
                                  mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
                                  oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
                                  lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0,
-                                 c->box));
+                                 c->box, part, part_lo, part_hi));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -532,6 +536,7 @@ int loop_begin(fluid_ctx* c) {
     c->loop_halo = 0;
     c->loop_aux_halo = 0;
     c->loop_ghost_bg = false;
+    c->loop_part_done = 0;
     return rc;
 }
 // a working buffer that is neither a nor b
@@ -543,7 +548,8 @@ int other_buffer(int a, int b) {
 // Advance by one sweep, or by two in one pass (kernels_pressure_fused.h).  With two, the
 // intermediate iterate is kept only when `keep_mid` (the last pair of an even-length loop: iterate
 // N-1 is what PRESSURES_2 must hold).  Returns the buffer written with the newest iterate.
-int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
+int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int part = FUSED_WHOLE,
+                 int part_lo = 0, int part_hi = 0) {
     int rc = FLUID_OK;
     const int cur = c->loop_cur;
     if (c->is_slab && c->loop_halo < (int)sweeps)
@@ -551,12 +557,36 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
                        "%u sweep(s) need %u valid ghost plane(s) of the newest iterate, %d left: "
                        "exchange halos and call fluid_pressure_loop_halo_exchanged",
                        sweeps, sweeps, c->loop_halo);
+    // a pass in two launches (FUSED_EDGES / FUSED_INTERIOR, either order): the second one commits
+    bool commit = true;
+    if (part != FUSED_WHOLE) {
+        if (sweeps != 2)
+            return c->fail(FLUID_ERR_INVALID_ARG, "only a two-sweep pass can be split into parts");
+        if (c->loop_part_done == 0) {
+            c->loop_part_done = part;
+            c->loop_part_keep = keep_mid;
+            c->loop_part_lo = part_lo;
+            c->loop_part_hi = part_hi;
+            commit = false;
+        } else if (c->loop_part_done == part || c->loop_part_keep != keep_mid ||
+                   c->loop_part_lo != part_lo || c->loop_part_hi != part_hi) {
+            return c->fail(FLUID_ERR_INVALID_ARG,
+                           "the second part of a split pass must be the other part with the same "
+                           "arguments");
+        } else {
+            c->loop_part_done = 0;
+        }
+    } else if (c->loop_part_done != 0) {
+        return c->fail(FLUID_ERR_INVALID_ARG, "a split pass is half done: launch its other part");
+    }
     if (sweeps == 2) {
         const int dst = other_buffer(cur, cur);
         const int mid = keep_mid ? other_buffer(cur, dst) : -1;
         rc = ensure_background(c, dst);
         if (rc == FLUID_OK && mid >= 0) rc = ensure_background(c, mid);
-        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid);
+        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid, part, part_lo, part_hi);
+        if (written) *written = dst;
+        if (!commit) return rc;
         c->loop_prev = mid;
         c->loop_cur = dst;
         c->loop_k += 2;
@@ -574,6 +604,8 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written) {
     return rc;
 }
 int loop_end(fluid_ctx* c) {
+    if (c->loop_part_done != 0)
+        return c->fail(FLUID_ERR_INVALID_ARG, "a split pass is half done: launch its other part");
     c->loop_open = false;
     c->pressure_dispatch_index = c->loop_k;
     if (c->loop_k == 0) return FLUID_OK;
@@ -1182,6 +1214,28 @@ int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermed
     int rc2 = tm.end();
     if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && sweeps == 2)
         c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += 1;  // count sweeps
+    return rc ? rc : rc2;
+}
+
+int fluid_pressure_loop_advance_part(fluid_ctx* c, int keep_intermediate, int part,
+                                     int32_t interior_begin, int32_t interior_end,
+                                     int* written_buffer) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
+    if (!fuse_enabled(c))
+        return c->fail(FLUID_ERR_UNSUPPORTED, "split passes need the two-sweeps-per-pass kernel");
+    if (part != FLUID_LOOP_PART_EDGES && part != FLUID_LOOP_PART_INTERIOR)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown part %d", part);
+    if (interior_end < interior_begin)
+        return c->fail(FLUID_ERR_INVALID_ARG, "interior planes [%d, %d)", interior_begin, interior_end);
+    HIP_TRY(c, hipSetDevice(c->device));
+    SectionTimer tm{c};
+    int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
+    if (rc) return rc;
+    rc = loop_advance(c, 2, keep_intermediate != 0, written_buffer,
+                      part == FLUID_LOOP_PART_EDGES ? FUSED_EDGES : FUSED_INTERIOR, interior_begin,
+                      interior_end);
+    int rc2 = tm.end();  // two launches = two timer calls = the pass's two sweeps in sec_calls
     return rc ? rc : rc2;
 }
 

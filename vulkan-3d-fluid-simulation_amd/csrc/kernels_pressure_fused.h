@@ -65,8 +65,12 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
 //   [mlo, mhi)          same for mask / b_i
 //   ytile0              first row tile of the launch (blockIdx.y = 0); launches of sparse scenes cover
 //                       only the tiles and planes around the water (ActiveBox, pressure_api.h)
+//   [hole_lo, hole_hi)  planes inside [zout_lo, zout_hi) this launch leaves out (a Z slab computes the
+//                       planes near its faces and the planes in between in separate launches, so that
+//                       the halo exchange overlaps the larger one); nz_lo = z-chunks below the hole.
+//                       No hole: hole_lo = hole_hi = zout_hi, nz_lo = all chunks.
 struct FusedRange {
-    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0;
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo;
 };
 
 // Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
@@ -244,8 +248,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.x0 = tx * 256 + c.lane * 4;
     const int y0 = ((int)blockIdx.y + rg.ytile0) * TY;  // first output row
     const int y = y0 - 1 + c.rr;           // this wavefront's row
-    c.zb = rg.zout_lo + blockIdx.z * zchunk;
-    c.ze = min(c.zb + zchunk, rg.zout_hi);
+    if ((int)blockIdx.z < rg.nz_lo) {
+        c.zb = rg.zout_lo + blockIdx.z * zchunk;
+        c.ze = min(c.zb + zchunk, rg.hole_lo);
+    } else {
+        c.zb = rg.hole_hi + ((int)blockIdx.z - rg.nz_lo) * zchunk;
+        c.ze = min(c.zb + zchunk, rg.zout_hi);
+    }
 
     if (c.zb >= 0 && c.ze <= g.Dl) {
         // the whole group leaves if no brick it touches holds water (uniform: before any barrier);

@@ -61,7 +61,10 @@ void k12_launch_canon(hipStream_t s, int rows_per_wave, const uint8_t* mask, con
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                              float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
-                             const ActiveBox& box);
+                             const ActiveBox& box, int part = 0, int part_lo = 0, int part_hi = 0);
+// `part`: the whole pass, or one of the two launches a Z slab splits it into — FUSED_INTERIOR writes
+// the output planes [part_lo, part_hi) (clipped to the pass's output range), FUSED_EDGES the rest
+enum { FUSED_WHOLE = 0, FUSED_EDGES = 1, FUSED_INTERIOR = 2 };
 bool k12_canon2_supports(const GridK& g);
 
 }  // namespace fluid

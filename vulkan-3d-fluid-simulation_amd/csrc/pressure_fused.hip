@@ -67,7 +67,8 @@ static int cu_count() {
 template <int NT>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                            float p_oob, const FusedRange& rg, const ActiveBox& box) {
+                            float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
+                            int part_lo, int part_hi) {
     static bool attr_set = false;  // per process and instantiation; the attribute is per function
     const size_t lds = fused_lds_bytes(NT);
     if (!attr_set) {
@@ -91,15 +92,32 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     }
     r.ytile0 = ty0;
     const int by = ty1 - ty0;
-    const int depth = r.zout_hi - r.zout_lo;
-    int zchunk = pick_zchunk(by, depth, cu_count());
+    // planes to compute: [zout_lo, zout_hi) minus the hole [part_lo, part_hi) (part = edges), or only
+    // the hole (part = interior); whole pass otherwise
+    if (part != FUSED_WHOLE) {
+        const int a = std::min(std::max(part_lo, r.zout_lo), r.zout_hi);
+        const int b = std::min(std::max(part_hi, a), r.zout_hi);
+        if (part == FUSED_INTERIOR) {
+            r.zout_lo = a;
+            r.zout_hi = b;
+        } else {
+            r.hole_lo = a;
+            r.hole_hi = b;
+        }
+    }
+    if (part != FUSED_EDGES) r.hole_lo = r.hole_hi = r.zout_hi;
+    const int seg1 = r.hole_lo - r.zout_lo, seg2 = r.zout_hi - r.hole_hi;
+    const int depth = std::max(seg1, seg2);
+    if (depth <= 0) return hipSuccess;
+    int zchunk = std::min(pick_zchunk(by, depth, cu_count()), depth);
     // Sparse scene without a box (Z slab: the ghost planes are not covered by the activity map): most
     // workgroups leave at once and the few that work should be short, so that they run side by side.
     if (!box.valid && box.fraction >= 0.f &&
         box.fraction * by * ((depth + zchunk - 1) / zchunk) < 0.75f * cu_count())
         zchunk = std::min(zchunk, 24);
     if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
-    const dim3 grid(1, by, (depth + zchunk - 1) / zchunk);
+    r.nz_lo = (seg1 + zchunk - 1) / zchunk;
+    const dim3 grid(1, by, r.nz_lo + (seg2 + zchunk - 1) / zchunk);
     BrickK bk;
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
@@ -112,7 +130,7 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                              float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
-                             const ActiveBox& box) {
+                             const ActiveBox& box, int part, int part_lo, int part_hi) {
     // halo_lo / halo_hi: valid ghost planes of the input below / above the owned planes (0 at a
     // domain face); aux_*: the same for mask and b_i.  A launch consumes two planes of halo.
     FusedRange rg;
@@ -123,10 +141,15 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.zout_lo = -std::max(0, std::min(halo_lo - 2, aux_lo - 1));
     rg.zout_hi = g.Dl + std::max(0, std::min(halo_hi - 2, aux_hi - 1));
     rg.ytile0 = 0;
+    rg.hole_lo = rg.hole_hi = rg.zout_hi;
+    rg.nz_lo = 0;
     const int nt = (g.W + 255) / 256;
-    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
-    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
-    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box);
+    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                     part_lo, part_hi);
+    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                     part_lo, part_hi);
+    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                     part_lo, part_hi);
     return hipErrorInvalidValue;
 }
 

@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
+    "fluid_pressure_loop_advance_part",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
     "fluid_get_geometry", "fluid_set_option",
@@ -138,6 +139,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
         "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
+        "fluid_pressure_loop_advance_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, C.c_int32,
+                                                       C.POINTER(C.c_int)]),
         "fluid_pressure_loop_halo_exchanged": (C.c_int, [vp, u32, u32]),
         "fluid_pressure_loop_end": (C.c_int, [vp]),
         "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
@@ -369,6 +372,18 @@ class FluidEngine:
         self._check(self._lib.fluid_pressure_loop_advance(self._h, sweeps,
                                                           1 if keep_intermediate else 0,
                                                           C.byref(written)))
+        return int(written.value)
+
+    LOOP_PART_EDGES, LOOP_PART_INTERIOR = 1, 2
+
+    def pressure_loop_advance_part(self, keep_intermediate: bool, part: int, interior_begin: int,
+                                   interior_end: int) -> int:
+        """One of the two launches of a split two-sweep pass (include/fluid_engine.h)."""
+        written = C.c_int(-1)
+        lo = max(int(interior_begin), -2 ** 31)
+        hi = min(int(interior_end), 2 ** 31 - 1)
+        self._check(self._lib.fluid_pressure_loop_advance_part(
+            self._h, 1 if keep_intermediate else 0, part, lo, hi, C.byref(written)))
         return int(written.value)
 
     def pressure_loop_halo_exchanged(self, depth: int, aux_depth: int = 0):

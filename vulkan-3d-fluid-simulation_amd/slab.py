@@ -87,6 +87,7 @@ class GpuSlabCompute:
         # kernels and the communicator's stream-ordering both follow it.  (The legacy null stream
         # has handle 0, which the C ABI reads as "create your own".)
         self.stream = torch.cuda.Stream(device=device)
+        self.comm_stream = None  # created by the first overlapped exchange
         torch.cuda.set_stream(self.stream)
         self.arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         base = self.arena.data_ptr()
@@ -147,13 +148,45 @@ class GpuSlabCompute:
     def loop_max_sweeps(self) -> int:
         return self.engine.pressure_loop_max_sweeps() if self.fast else 1
 
-    def loop_advance(self, k: int, sweeps: int, keep_mid: bool) -> int:
-        """Sweeps k .. k+sweeps-1.  Returns the buffer that now holds the newest iterate."""
+    def loop_advance(self, k: int, sweeps: int, keep_mid: bool, part: Optional[str] = None,
+                     interior: Optional[Tuple[int, int]] = None) -> int:
+        """Sweeps k .. k+sweeps-1.  Returns the buffer that now holds the newest iterate.
+        `part` = "edges" / "interior": one of the two launches of a split two-sweep pass; the output
+        planes [interior[0], interior[1]) are the interior (include/fluid_engine.h)."""
         if self.fast:
+            if part is not None:
+                assert sweeps == 2
+                which = (self.engine.LOOP_PART_EDGES if part == "edges"
+                         else self.engine.LOOP_PART_INTERIOR)
+                return self.engine.pressure_loop_advance_part(keep_mid, which, *interior)
             return self.engine.pressure_loop_advance(sweeps, keep_mid)
-        assert sweeps == 1
+        assert sweeps == 1 and part is None
         self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
         return (k + 1) % 2
+
+    # ---- a halo exchange that runs beside compute: a second stream, ordered by events ----
+    can_overlap = True
+
+    def comm_scope(self):
+        """Context in which the exchange is issued: the communication stream, which first waits for
+        everything launched on the compute stream so far."""
+        torch = self.torch
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.comm_stream.wait_event(ev)
+        return torch.cuda.stream(self.comm_stream)
+
+    def comm_mark(self):
+        """Call inside comm_scope() after the exchange has been issued (and stream-waited for)."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.comm_stream)
+        return ev
+
+    def comm_join(self, mark):
+        """Launches on the compute stream from here on come after the exchange."""
+        self.stream.wait_event(mark)
 
     def loop_end(self):
         if self.fast:
@@ -274,8 +307,55 @@ class HostSlabCompute:
         self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
                       self.work[src].numpy(), self.work[dst].numpy())
 
-    def loop_advance(self, k: int, sweeps: int, keep_mid: bool):
+    can_overlap = True
+
+    def comm_scope(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def comm_mark(self):
+        return None
+
+    def comm_join(self, mark):
+        pass
+
+    def _split_pass(self, keep_mid: bool, part: str, interior):
+        """One launch of a split pass: two sweeps from `cur` into scratch copies, of which only this
+        part's planes are stored — so a part that (wrongly) depended on ghost planes still in flight
+        would show up as a mismatch."""
+        dst = self._other(self.cur, self.cur)
+        mid = self._other(self.cur, dst)
+        t_mid, t_dst = self.work[mid].clone(), self.work[dst].clone()
+        self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
+                      self.work[self.cur].numpy(), t_mid.numpy())
+        self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
+                      t_mid.numpy(), t_dst.numpy())
+        n = self.dl + 2 * self.GW
+        a = min(max(interior[0] + self.GW, 0), n)
+        b = min(max(interior[1] + self.GW, a), n)
+        ranges = [(a, b)] if part == "interior" else [(0, a), (b, n)]
+        for lo, hi in ranges:
+            self.work[dst][lo:hi] = t_dst[lo:hi]
+            self.work[mid][lo:hi] = t_mid[lo:hi]
+        if self._part_done is None:
+            self._part_done = part
+            return dst
+        assert self._part_done != part
+        self._part_done = None
+        self.prev = mid if keep_mid else -1
+        self.cur = dst
+        self.k += 2
+        return dst
+
+    _part_done = None
+
+    def loop_advance(self, k: int, sweeps: int, keep_mid: bool, part=None, interior=None):
         assert k == self.k
+        if part is not None:
+            assert sweeps == 2
+            return self._split_pass(keep_mid, part, interior)
+        assert self._part_done is None
         if sweeps == 2:
             dst = self._other(self.cur, self.cur)
             mid = self._other(self.cur, dst)
@@ -324,6 +404,9 @@ class SlabPressureSolver:
         # per sweep, h times fewer messages and host round trips).  Clipped to what the compute
         # backend and the slab thickness allow; even, so sweeps can go in pairs.
         self.halo_depth = halo_depth
+        # run halo exchanges beside the passes that do not need them (solve()); FLUID_SLAB_OVERLAP=0
+        # turns it off
+        self.overlap = os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0"
         # transport "direct": the communicator addresses the planes where they live (RCCL on
         # device memory, gloo on host memory).  "staged": bounce through host tensors — only for
         # rehearsing the GPU slab path over gloo on a box with a single GPU (tests).
@@ -338,6 +421,7 @@ class SlabPressureSolver:
         self._plans = {}
         self._ops = {}
         self.exchanges = 0  # halo exchanges performed (diagnostics)
+        self.overlapped = 0  # ... of which started beside a split pass
 
     @classmethod
     def create_gpu(cls, size, iterations: int, ctx: DistContext, pressure_kernel: int = 0,
@@ -362,10 +446,16 @@ class SlabPressureSolver:
         """Send the first/last `width` owned planes to the lower/upper neighbour, receive their
         last/first owned planes into the ghost planes.  Grouped point-to-point, both directions at
         once.  Tensor views and P2POps are built once per buffer and reused (planes never move)."""
+        self._finish_plan(self._start_plan(key, make_planes, width, overlapped=False))
+
+    def _start_plan(self, key, make_planes, width: int, overlapped: bool):
+        """Issue the exchange; `_finish_plan(handle)` before anything may touch the received planes.
+        overlapped: issue it on the compute backend's communication stream (ordered after what has
+        been launched so far), so that launches made between start and finish run beside it."""
         import torch.distributed as dist
 
         if self.ctx.world == 1 and self.transport != "loopback":
-            return
+            return None
         self.exchanges += 1
         if self.z_count < width:
             raise RuntimeError(f"slab of {self.z_count} planes is thinner than the halo ({width})")
@@ -380,15 +470,9 @@ class SlabPressureSolver:
                 plan.append((True, make_planes(n - width, width), self.hi))
                 plan.append((False, make_planes(n, width), self.hi))
             self._plans[key] = plan
-        if self.transport == "loopback":
-            # single-process rehearsal of one rank's work (tools/slab_rank_sim.py): every receive is
-            # filled by a device copy of a send buffer of the same size; no communicator involved
-            sends = [t for snd, t, _ in plan if snd]
-            recvs = [t for snd, t, _ in plan if not snd]
-            for i, r in enumerate(recvs):
-                r.copy_(sends[(i + 1) % len(sends)])
-            return
         if self.transport == "staged":
+            # through host tensors, synchronously (t.cpu() waits for the compute stream): rehearses
+            # the schedule of the GPU path over gloo on a box with one GPU; nothing overlaps
             staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
                       for snd, t, peer in plan]
             ops = [dist.P2POp(dist.isend if snd else dist.irecv, h, peer)
@@ -398,13 +482,46 @@ class SlabPressureSolver:
             for snd, h, t, _ in staged:
                 if not snd:
                     t.copy_(h)
+            return None
+        scope = self.compute.comm_scope() if overlapped else None
+        if scope is not None:
+            scope.__enter__()
+        try:
+            if self.transport == "loopback":
+                # single-process rehearsal of one rank's work (tools/slab_rank_sim.py): every receive
+                # is filled by a device copy of a send buffer of the same size; no communicator
+                sends = [t for snd, t, _ in plan if snd]
+                recvs = [t for snd, t, _ in plan if not snd]
+                for i, r in enumerate(recvs):
+                    r.copy_(sends[(i + 1) % len(sends)])
+                works = []
+            else:
+                ops = self._ops.get(key)
+                if ops is None:
+                    ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer)
+                           for snd, t, peer in plan]
+                    self._ops[key] = ops
+                works = dist.batch_isend_irecv(ops)
+            if not overlapped:
+                return ("works", works)
+            if self.ctx.backend == "nccl":
+                # stream-level wait (the host does not block): the communication stream now ends
+                # with the exchange, and the mark below is what the compute stream joins on
+                for work in works:
+                    work.wait()
+                works = []
+            return ("overlapped", works, self.compute.comm_mark())
+        finally:
+            if scope is not None:
+                scope.__exit__(None, None, None)
+
+    def _finish_plan(self, handle):
+        if handle is None:
             return
-        ops = self._ops.get(key)
-        if ops is None:
-            ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer) for snd, t, peer in plan]
-            self._ops[key] = ops
-        for work in dist.batch_isend_irecv(ops):
+        for work in handle[1]:
             work.wait()
+        if handle[0] == "overlapped":
+            self.compute.comm_join(handle[2])
 
     def exchange(self, image_id: int):
         """One-plane halo exchange of an image (cell types at set-up)."""
@@ -432,7 +549,13 @@ class SlabPressureSolver:
         k+1; after N dispatches PRESSURES_1 holds the last even iterate, PRESSURES_2 the last odd one.
         Every sweep consumes one valid ghost plane per side; when fewer are left than the next
         launch needs (2 for a two-sweeps-per-pass launch), `h` boundary planes of the newest iterate
-        are exchanged with the two Z-neighbours."""
+        are exchanged with the two Z-neighbours.
+
+        Overlap (self.overlap, h >= 4, slabs thicker than 2h): the pass before an exchange is split —
+        the h planes per face that will be sent are computed first, the exchange starts on the
+        communication stream, the planes in between follow —, and so is the pass after it: the
+        output planes that depend on owned planes only are computed while the exchange is in flight,
+        the rest once it has landed.  Same arithmetic, same iterates."""
         n = self.iterations if iterations is None else iterations
         c = self.compute
         h = self.effective_halo()
@@ -442,16 +565,47 @@ class SlabPressureSolver:
         valid = h          # valid ghost planes of the newest iterate
         cur = 0            # buffer holding it
         pair = c.loop_max_sweeps() >= 2 and h >= 2
+        thinnest = min(m for _, m in partition_z(self.size[2], self.ctx.world))
+        split = (self.overlap and pair and h >= 4 and thinnest > 2 * h
+                 and getattr(c, "can_overlap", False)
+                 and (self.ctx.world > 1 or self.transport == "loopback"))
+        big = 1 << 30
+        dl = self.z_count
+        # interior of the pass before an exchange / of the pass after it (local output planes)
+        before = (h if self.lo is not None else -big, dl - h if self.hi is not None else big)
+        after = (2 if self.lo is not None else -big, dl - 2 if self.hi is not None else big)
+        pending = None     # exchange in flight: finish before launching anything that reads ghosts
         k = 0
         while k < n:
             sweeps = 2 if (pair and n - k >= 2) else 1
-            if valid < sweeps:
+            keep = sweeps == 2 and n - k == 2
+            if pending is None and valid < sweeps:
                 self.exchange_loop_buffer(cur, h)
                 c.loop_halo_exchanged(h, False)
                 valid = h
-            cur = c.loop_advance(k, sweeps, sweeps == 2 and n - k == 2)
-            valid = valid - 2 if sweeps == 2 else 0
+            left = n - k - sweeps
+            next_sweeps = 2 if (pair and left >= 2) else min(left, 1)
+            valid_after = valid - 2 if sweeps == 2 else 0
+            if pending is not None:
+                # first pass after the exchange started: valid == h here (reported at the start)
+                c.loop_advance(k, 2, keep, "interior", after)
+                self._finish_plan(pending)
+                pending = None
+                cur = c.loop_advance(k, 2, keep, "edges", after)
+            elif split and sweeps == 2 and next_sweeps == 2 and valid_after < 2:
+                dst = c.loop_advance(k, 2, keep, "edges", before)
+                self.overlapped += 1
+                pending = self._start_plan(("loop", dst, h),
+                                           lambda z, m, b=dst: c.planes(b, z, m), h, overlapped=True)
+                cur = c.loop_advance(k, 2, keep, "interior", before)
+                assert cur == dst
+                c.loop_halo_exchanged(h, False)  # started; the next pass orders itself behind it
+                valid_after = h
+            else:
+                cur = c.loop_advance(k, sweeps, keep)
+            valid = valid_after
             k += sweeps
+        assert pending is None
         c.loop_end()
 
     def step(self):
