@@ -252,8 +252,11 @@ int fluid_run_section_loop(fluid_ctx* ctx, int section_id, uint32_t iterations);
  *   (FLUID_SEC_07_ADVECT, 2)                            exact
  *   (FLUID_SEC_09_DIFFUSE, 3)                           exact (FLUID_DIFFUSE_REFERENCE_EXACT)
  * Any other slice, or a grouped one whose precondition does not hold, runs section by section.
- * fluid_run_step uses these groups unless FLUID_OPT_STEP_FUSION = 1.  Not available on Z-slab
- * contexts (the caller exchanges ghost planes between sections there). */
+ * fluid_run_step uses these groups unless FLUID_OPT_STEP_FUSION = 1.
+ * Z-slab contexts: only these three slices (other slices need ghost planes from the neighbours in
+ * between).  Ghost planes they read: (04, 2) as 04 and 05; (07, 2) as 07; (09, 3) one plane of
+ * VELOCITIES_2 and of CELL_TYPES above the slab — exchange VELOCITIES_2 before the group instead of
+ * VELOCITIES_1 between 10 and 11. */
 int fluid_run_section_group(fluid_ctx* ctx, int first_section_id, uint32_t count);
 
 /* FlowClearColorSection(ctx, image, ClearValue) for an arbitrary image and value
@@ -342,6 +345,9 @@ int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void
  * from fluid_image_plane_ptr (halo exchange), so data the engine derives from it is rebuilt.
  * Ghost planes of PRESSURES_1/2 must carry the neighbouring slab's cells of the same buffer. */
 int fluid_notify_image_written(fluid_ctx* ctx, int image_id);
+/* The same when only ghost planes were written (a halo exchange): what the engine knows about the owned
+ * planes stays valid. */
+int fluid_notify_ghost_planes_written(fluid_ctx* ctx, int image_id);
 /* Z-slab contexts, full step.  The caller runs the sections one by one (fluid_run_section) and
  * exchanges ghost planes between them (fluid_image_plane_ptr, FLUID_IMAGE_GHOST_PLANES per side):
  *   after 02 and after 03: NEW_CELL_TYPES, 1 plane          (03 / 05 read z-1, z+1)
@@ -350,6 +356,9 @@ int fluid_notify_image_written(fluid_ctx* ctx, int image_id);
  *   after the pressure loop: PRESSURES_2, 1 plane           (13 reads z-1)
  *   after 13: VELOCITIES_1, FLUID_IMAGE_GHOST_PLANES planes (14 samples it)
  *   after 14: particle migration (below)
+ * With the grouped passes (fluid_run_section_group): 04+05 in place of 04, 05; 07+08 in place of 07,
+ * 08; and, instead of the one-plane VELOCITIES_1 exchange after 10, one plane of VELOCITIES_2 after 08
+ * followed by 09+10+11.
  * 06 copies one ghost plane per side along with the owned planes.  The velocity sampler of 07 / 14
  * can reach as far as the fluid moves in one step; a tap beyond the ghost planes raises the halo
  * violation flag (fluid_slab_status reads and clears it): results of that step are then not exact.

@@ -85,6 +85,20 @@ class HostGlobalCompute:
         for f in WRITES[name]:
             self._poison(f)
 
+    STEP_LIST = list(OracleState.STEP_BEFORE_12)
+
+    def run_section_group(self, first, count):
+        """The sections of the slice back to back, poisoning afterwards: inside a grouped pass the
+        engine computes from ghost planes what the list would have exchanged in between."""
+        i = self.STEP_LIST.index(first)
+        names = self.STEP_LIST[i:i + count]
+        with np.errstate(all="ignore"):
+            for name in names:
+                self.st.run_section(name)
+        for name in names:
+            for f in WRITES[name]:
+                self._poison(f)
+
     def upload(self, image_id, array):
         self._owned(getattr(self.st, IMAGE_FIELD[image_id]))[...] = array
 

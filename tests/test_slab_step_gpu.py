@@ -46,7 +46,7 @@ def drift(shape):
     return v
 
 
-def _worker(rank, world, port, size, iters, steps, out_dir):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -64,7 +64,7 @@ def _worker(rank, world, port, size, iters, steps, out_dir):
     torch.cuda.set_device(0)
     ctx = DistContext(rank, world, torch.device("cuda", 0), "gloo")
     params, cap = scene_params(size)
-    sim = SlabSimulation(params, cap, iters, ctx, transport="staged")
+    sim = SlabSimulation(params, cap, iters, ctx, transport="staged", grouped=grouped)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
@@ -83,14 +83,18 @@ def _worker(rank, world, port, size, iters, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,steps", [(2, (32, 24, 16), 12, 6), (3, (64, 16, 24), 9, 5)])
-def test_slab_simulation_matches_oracle(world, size, iters, steps, tmp_path):
+@pytest.mark.parametrize("world,size,iters,steps,grouped", [
+    (2, (32, 24, 16), 12, 6, True), (3, (64, 16, 24), 9, 5, True),
+    (2, (32, 24, 16), 12, 4, False),  # the section list, one kernel per section
+    (2, (30, 24, 16), 12, 4, True),   # width not a multiple of 4
+])
+def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal
     from oracle_binding import OracleState
 
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, str(tmp_path)),
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path)),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     params, cap = scene_params(size)

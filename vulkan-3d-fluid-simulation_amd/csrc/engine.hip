@@ -1380,7 +1380,17 @@ int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) 
         return c->fail(FLUID_ERR_INVALID_ARG,
                        "sections [%d, %d + %u) are not a slice of the step section list",
                        first_section_id, first_section_id, count);
-    if (c->is_slab) return slab_unsupported(c, "fluid_run_section_group");
+    if (c->is_slab) {
+        // between most sections of the list a slab needs ghost planes from its neighbours: only the
+        // grouped passes themselves are slices a slab can run in one call
+        const bool g0405 = first_section_id == FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES && count == 2;
+        const bool g0708 = first_section_id == FLUID_SEC_07_ADVECT && count == 2;
+        const bool g0911 = first_section_id == FLUID_SEC_09_DIFFUSE && count == 3 &&
+                           c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT && c->g.W % 4 == 0;
+        if (!g0405 && !g0708 && !g0911)
+            return slab_unsupported(c, "this slice of the step list in one call (only 04+05, 07+08 "
+                                       "and, for fluid_size.x % 4 == 0, 09+10+11)");
+    }
     return run_step_slice(c, first_section_id, (int)count, true);
 }
 
@@ -1441,6 +1451,16 @@ int fluid_notify_image_written(fluid_ctx* c, int image_id) {
     int rc = check_image(c, image_id);
     if (rc) return rc;
     c->touched(image_id);  // derived data (neighbour mask, b_i, working-buffer constants) is rebuilt
+    return FLUID_OK;
+}
+
+int fluid_notify_ghost_planes_written(fluid_ctx* c, int image_id) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    const bool w0 = c->v1_w_zero;  // a property of the owned planes
+    c->touched(image_id);
+    c->v1_w_zero = w0;
     return FLUID_OK;
 }
 

@@ -20,7 +20,9 @@
 //
 // Arithmetic is the per-section kernels' (same operations, same order): results are bit-identical,
 // which tests/test_engine_parity_gpu.py checks against the oracle and against the section list.
-// Whole-grid contexts only (a Z slab exchanges ghost planes between these sections).
+// On a Z slab the caller exchanges ghost planes around a group instead of inside it: 04+05 and 07+08
+// need what 04 / 07 need; 09+10+11 needs one ghost plane of VELOCITIES_2 (and of CELL_TYPES) above the
+// slab instead of one of VELOCITIES_1 between 10 and 11.
 #pragma once
 
 #include "device_common.h"
@@ -154,6 +156,7 @@ __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
     const int lz = blockIdx.z;
     if (x >= g.W || y >= g.H) return;
     const int64_t id = cidx(g, x, y, lz);
+    const int gz = g.z0 + lz;
     const float r = p.repel;
     const float4 q = v2[id];  // diffuse.comp:34,46: the copy
     const bool solid = (uint32_t)t[id] == p.t_solid;
@@ -169,7 +172,7 @@ __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
         ax = solids_component(v2[id + 1].x, (uint32_t)t[id + 1] == p.t_solid, solid, r);
     if (y + 1 < g.H)
         ay = solids_component(v2[id + g.W].y, (uint32_t)t[id + g.W] == p.t_solid, solid, r);
-    if (lz + 1 < g.Dl)
+    if (gz + 1 < g.Dg)  // on a Z slab the plane above the slab is a ghost plane of VELOCITIES_2 / types
         az = solids_component(v2[id + g.plane].z, (uint32_t)t[id + g.plane] == p.t_solid, solid, r);
     float d = ax - vx;  // :21 left to right
     d = d + ay;

@@ -62,6 +62,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
+    "fluid_notify_ghost_planes_written",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
     "fluid_pressure_loop_advance_part",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
@@ -136,6 +137,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_reset_timing": (C.c_int, [vp]),
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
+        "fluid_notify_ghost_planes_written": (C.c_int, [vp, C.c_int]),
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
         "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
@@ -419,6 +421,9 @@ class FluidEngine:
 
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))
+
+    def notify_ghost_planes_written(self, image_id: int):
+        self._check(self._lib.fluid_notify_ghost_planes_written(self._h, image_id))
 
     def image_plane_ptr(self, image_id: int, plane: int):
         ptr, nbytes = C.c_void_p(), C.c_uint64()

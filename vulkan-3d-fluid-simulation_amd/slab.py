@@ -203,7 +203,10 @@ class GpuSlabCompute:
         self.torch.cuda.synchronize(self.device)
 
     def halo_written(self, image_id: int):
-        self.engine.notify_image_written(image_id)
+        self.engine.notify_ghost_planes_written(image_id)
+
+    def run_section_group(self, first: str, count: int):
+        self.engine.run_section_group(first, count)
 
     # ---- full step on slabs -----------------------------------------------------------------------
     IMAGE_GHOST = E.FluidEngine.IMAGE_GHOST_PLANES
@@ -674,7 +677,10 @@ class SlabSimulation:
     (checked every step)."""
 
     def __init__(self, params: FluidParams, particle_capacity: int, iterations: int, ctx: DistContext,
-                 compute=None, transport: str = "direct", halo_depth: int = 8):
+                 compute=None, transport: str = "direct", halo_depth: int = 8, grouped: bool = True):
+        # grouped: 04+05, 07+08 and 09+10+11 as single passes (include/fluid_engine.h:
+        # fluid_run_section_group); 09+10+11 needs fluid_size.x % 4 == 0
+        self.grouped = grouped
         self.params = params
         self.ctx = ctx
         self.size = params.size
@@ -712,16 +718,26 @@ class SlabSimulation:
         x(E.NEW_CELL_TYPES, 1)                         # 03 looks at z-1 / z+1
         c.run_section("03_update_air")
         x(E.NEW_CELL_TYPES, 1)                         # 05 reads the final new types at z-1
-        c.run_section("04_compute_extrapolated_velocities")  # old types / V1 at z+-1: still current
-        c.run_section("05_set_extrapolated_velocities")
+        if self.grouped:                               # old types / V1 at z+-1: still current
+            c.run_section_group("04_compute_extrapolated_velocities", 2)
+        else:
+            c.run_section("04_compute_extrapolated_velocities")
+            c.run_section("05_set_extrapolated_velocities")
         x(E.VELOCITIES_1, self.ghost)                  # 07 samples V1 around each cell
         c.run_section("06_update_cell_types")          # carries one ghost plane per side along
-        c.run_section("07_advect")
-        c.run_section("08_forces")
-        c.run_section("09_diffuse")
-        c.run_section("10_solids")
-        x(E.VELOCITIES_1, 1)                           # 11 reads V1 at z+1
-        c.run_section("11_compute_divergence")
+        if self.grouped:
+            c.run_section_group("07_advect", 2)
+        else:
+            c.run_section("07_advect")
+            c.run_section("08_forces")
+        if self.grouped and self.size[0] % 4 == 0:
+            x(E.VELOCITIES_2, 1)                       # 11, on what 10 makes of V2 at z+1
+            c.run_section_group("09_diffuse", 3)
+        else:
+            c.run_section("09_diffuse")
+            c.run_section("10_solids")
+            x(E.VELOCITIES_1, 1)                       # 11 reads V1 at z+1
+            c.run_section("11_compute_divergence")
         self.pressure.step()                           # 12a, 12b, the 12_solve_pressure loop
         x(E.PRESSURES_2, 1)                            # 13 reads P2 at z-1
         c.run_section("13_fix_divergence")
