@@ -1,0 +1,54 @@
+/* TEST INFRASTRUCTURE.  CPU check of the division-free quotient used by the two-sweeps-per-pass Jacobi
+ * kernel (vulkan-3d-fluid-simulation_amd/csrc/kernels_pressure_fused.h: div_small_int):
+ *
+ *     q0 = n * r;  e = fma(-q0, a, n);  q = fma(e, r, q0)      with r = RN(1/a)
+ *
+ * against the IEEE division n / a of pressure.comp:62, bit for bit, for a = 1..6 and every fp32 n that
+ * v_div_fixup_f32 passes through (finite, non-zero).  The kernel takes this path only when all |n| of
+ * a wavefront are >= 2^-90 (GUARD below), so mismatches below the guard are reported but allowed.
+ *
+ *   divide_small_int_check            every 4099th bit pattern plus the ends of every binade (seconds)
+ *   divide_small_int_check full       all 2^32 patterns per divisor (about a minute on 8 cores)
+ * Exit status 0 = no mismatch at or above the guard.  Build: gcc -O2 -mfma -fopenmp -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+static inline float as_f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+static inline uint32_t as_u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+#define GUARD_BITS 0x12800000u /* 2^-90 */
+
+static int differs(uint32_t u, float a, float r) {
+    const float n = as_f(u);
+    volatile float q0 = n * r; /* volatile: one rounding, no contraction with the next line */
+    const float e = fmaf(-q0, a, n);
+    const float q = fmaf(e, r, q0);
+    return as_u(q) != as_u(n / a);
+}
+
+int main(int argc, char** argv) {
+    const int full = argc > 1 && strcmp(argv[1], "full") == 0;
+    unsigned long long above = 0, below = 0, checked = 0;
+    for (int ai = 1; ai <= 6; ai++) {
+        const float a = (float)ai, r = 1.0f / a;
+        unsigned long long bad_above = 0, bad_below = 0, cnt = 0;
+#pragma omp parallel for reduction(+ : bad_above, bad_below, cnt) schedule(static)
+        for (long long i = 0; i < (1LL << 32); i++) {
+            const uint32_t u = (uint32_t)i, mag = u & 0x7FFFFFFFu, frac = u & 0x7FFFFFu;
+            if ((mag >> 23) == 0xFFu || mag == 0u) continue; /* inf, NaN, zero: v_div_fixup_f32 */
+            if (!full && (i % 4099) != 0 && frac > 64u && frac < 0x7FFFFFu - 64u) continue;
+            cnt++;
+            if (differs(u, a, r)) {
+                if (mag >= GUARD_BITS) bad_above++; else bad_below++;
+            }
+        }
+        printf("a=%d r=%08x checked=%llu mismatches: %llu at |n| >= 2^-90, %llu below\n", ai, as_u(r),
+               cnt, bad_above, bad_below);
+        above += bad_above; below += bad_below; checked += cnt;
+    }
+    printf("%s: %llu values checked, %llu mismatches above the guard, %llu below\n",
+           full ? "full" : "sampled", checked, above, below);
+    return above == 0 ? 0 : 1;
+}

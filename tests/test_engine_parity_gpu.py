@@ -575,3 +575,46 @@ def test_pressure_split_passes_equal_whole_passes(size):
         eng.pressure_loop_end()
         st.solve_pressure(8)
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="split passes: ")
+
+
+@pytest.mark.parametrize("iters", [2, 3, 6])
+def test_pressure_division_special_values(iters):
+    """The fused kernel replaces the IEEE division n / aii by a three-instruction exact quotient plus
+    v_div_fixup_f32 (kernels_pressure_fused.h).  Isolated water cells with every neighbour count
+    aii = 0..6 and numerators that are zeros, infinities, NaN, denormals, the extremes of the normal
+    range and values on both sides of the kernel's 2^-90 guard: bit-identical to the oracle."""
+    w, h, d = 64, 48, 12
+    p = default_params(w, h, d, 0)
+    p.time_delta = 1.0      # b_i = ((div * rho) * dx) / dt = div exactly
+    p.cell_width = 1.0
+    p.fluid_density = 1.0
+    p.pressure_air = 0.0    # dry neighbours contribute 0: the numerator is -b_i
+    st = OracleState(p, 0, iters)
+    st.cell_types[...] = CELL_AIR
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-40, -3e-39,
+                         2.0 ** -126, -(2.0 ** -126), 1.7e-38, 2.0 ** -100, 2.0 ** -91, -(2.0 ** -90),
+                         2.0 ** -89, 3.0, -7.0, 1.0 / 3.0, 3.4028234e38, -3.4028234e38, 1e30, 5e-324],
+                        np.float32)
+    solid_dirs = [(0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)]
+    k = 0
+    cells = []
+    for z in range(2, d - 2, 3):
+        for y in range(2, h - 2, 3):
+            for x in range(2, w - 2, 3):
+                nsolid = k % 7
+                st.cell_types[z, y, x] = CELL_WATER
+                for dz, dy, dx in solid_dirs[:nsolid]:
+                    st.cell_types[z + dz, y + dy, x + dx] = CELL_SOLID
+                st.divergences[z, y, x] = specials[(k // 7) % len(specials)]
+                cells.append((z, y, x))
+                k += 1
+    assert k >= 7 * len(specials)
+    with make_engine(st) as eng, np.errstate(all="ignore"):
+        for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
+            eng.run_section(name)
+            st.run_section(name)
+        eng.solve_pressure(iters)
+        st.solve_pressure(iters)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="special values: ")
+    got = np.array([st.pressures_1[c] for c in cells[:7 * len(specials)]])
+    assert np.isnan(got).any() and np.isinf(got).any() and (got == 0).any()

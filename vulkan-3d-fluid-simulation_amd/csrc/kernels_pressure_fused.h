@@ -46,6 +46,67 @@ __device__ __forceinline__ void st_f4(float* base, unsigned byte_off, float4 v) 
     *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// ---- the division of pressure.comp:62 without the IEEE division sequence -----------------------------
+// A water cell's new pressure is n / aii with n = -s and aii in {0..6} (its mask byte).  hipcc expands an
+// fp32 division into ~11 VALU instructions (v_div_scale x2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup),
+// about 40 % of this kernel's arithmetic, and the kernel is issue-bound.  For a divisor known to be a
+// small integer the correctly rounded quotient takes three:
+//     q0 = n * r;  e = fma(-q0, a, n);  q = fma(e, r, q0)          with r = RN(1/a) from a table
+// (Markstein's correction step: e is the exact remainder).  tests/divide_small_int_check.c compares
+// this chain with n / a for ALL 2^32 fp32 values of n and a = 1..6 on the CPU: bit-identical except
+// for a = 6 with |n| < 2^-125; a wave-uniform test sends any wavefront holding |n| < 2^-90 down the
+// IEEE path instead (never taken in practice; 2^-90 also keeps e out of the denormal range, so the
+// result does not depend on the kernel's denormal mode).  v_div_fixup_f32 — the last instruction of
+// the IEEE sequence, with the same operands — supplies the IEEE results for n = +-0, inf, NaN and
+// a = 0 (inf / NaN), bit for bit what the division gives.
+struct DivEntry {
+    float a, r;
+};
+constexpr int DIV_TABLE_ENTRIES = 9;  // mask bytes 0..6 (aii) and MASK_DRY (result unused)
+__device__ __forceinline__ float2 lds_ld2(const FLUID_LDS char* base, uint32_t byte_off) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = *(const FLUID_LDS f32x2*)(base + byte_off);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float div_small_int(float n, float2 ar) {
+    const float q0 = n * ar.y;
+    const float e = __builtin_fmaf(-q0, ar.x, n);
+    const float q = __builtin_fmaf(e, ar.y, q0);
+    return __builtin_amdgcn_div_fixupf(q, ar.x, n);
+}
+// numerator of one water cell: -(b - sum of the six neighbours), pressure.comp:56-61 order
+__device__ __forceinline__ float canon_num(float b, float qxp, float qyp, float qzp, float qxm,
+                                           float qym, float qzm) {
+    float s = b;
+    s = s - qxp;
+    s = s - qyp;
+    s = s - qzp;
+    s = s - qxm;
+    s = s - qym;
+    s = s - qzm;
+    return -s;
+}
+// the four quotients of a lane: n / aii, aii = bytes of m
+__device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const FLUID_LDS char* table) {
+    const float tiny = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+    float4 o;
+    if (__builtin_amdgcn_ballot_w64(tiny < 0x1p-90f) == 0ull) {
+        const uint32_t m8 = m << 3;  // byte i of m8 = 8 * (mask byte i) = offset of its table entry
+        const float2 t0 = lds_ld2(table, m8 & 0xFFu), t1 = lds_ld2(table, (m8 >> 8) & 0xFFu);
+        const float2 t2 = lds_ld2(table, (m8 >> 16) & 0xFFu), t3 = lds_ld2(table, m8 >> 24);
+        o.x = div_small_int(n.x, t0);
+        o.y = div_small_int(n.y, t1);
+        o.z = div_small_int(n.z, t2);
+        o.w = div_small_int(n.w, t3);
+    } else {
+        o.x = n.x / (float)(m & 0xFFu);
+        o.y = n.y / (float)((m >> 8) & 0xFFu);
+        o.z = n.z / (float)((m >> 16) & 0xFFu);
+        o.w = n.w / (float)(m >> 24);
+    }
+    return o;
+}
+
 constexpr int FUSED_WAVES = 16;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int FUSED_PAD = 4;  // floats of padding on each side of an LDS row (keeps rows 16-B aligned)
@@ -53,7 +114,8 @@ constexpr int FUSED_PAD = 4;  // floats of padding on each side of an LDS row (k
 __host__ __device__ inline int fused_row_floats(int nt) { return nt * 256 + 2 * FUSED_PAD; }
 __host__ __device__ inline size_t fused_lds_bytes(int nt) {
     const int r = FUSED_WAVES / nt;
-    return (size_t)2 /*buffers*/ * 2 /*J,S*/ * r * fused_row_floats(nt) * sizeof(float);
+    return (size_t)2 /*buffers*/ * 2 /*J,S*/ * r * fused_row_floats(nt) * sizeof(float) +
+           128 /* DivEntry table */;
 }
 
 // Plane ranges of one launch (local plane indices; ghost planes are negative or >= Dl):
@@ -94,6 +156,7 @@ struct FusedCtx {
     float* pout;
     float* pmid;
     FLUID_LDS float* lds;
+    const FLUID_LDS char* divtab;  // DivEntry[DIV_TABLE_ENTRIES], behind the row buffers
     int64_t plane;
     int Dl, zb, ze;
     int jlo, jhi;  // local planes [jlo, jhi) of the working buffers hold cells of the grid: the owned
@@ -174,11 +237,12 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
         const float e = jrow[c.xe];
         const float left = from_lane_below(jc.w, e, c.lane);
         const float right = from_lane_above(jc.x, e, c.lane);
-        float4 o;
-        o.x = canon_cell(b_c.x, m_c, 0, jc.y, yp.x, jn.x, left, ym.x, jm.x);
-        o.y = canon_cell(b_c.y, m_c, 1, jc.z, yp.y, jn.y, jc.x, ym.y, jm.y);
-        o.z = canon_cell(b_c.z, m_c, 2, jc.w, yp.z, jn.z, jc.y, ym.z, jm.z);
-        o.w = canon_cell(b_c.w, m_c, 3, right, yp.w, jn.w, jc.z, ym.w, jm.w);
+        float4 n;
+        n.x = canon_num(b_c.x, jc.y, yp.x, jn.x, left, ym.x, jm.x);
+        n.y = canon_num(b_c.y, jc.z, yp.y, jn.y, jc.x, ym.y, jm.y);
+        n.z = canon_num(b_c.z, jc.w, yp.z, jn.z, jc.y, ym.z, jm.z);
+        n.w = canon_num(b_c.w, right, yp.w, jn.w, jc.z, ym.w, jm.w);
+        const float4 o = canon_div4(n, m_c, c.divtab);
         s_c.x = mask_is_water(m_c, 0) ? o.x : jc.x;
         s_c.y = mask_is_water(m_c, 1) ? o.y : jc.y;
         s_c.z = mask_is_water(m_c, 2) ? o.z : jc.z;
@@ -195,11 +259,12 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
             const float e = srow[c.xe];
             const float left = from_lane_below(s_m.w, e, c.lane);
             const float right = from_lane_above(s_m.x, e, c.lane);
-            float4 o;
-            o.x = canon_cell(b_m.x, m_m, 0, s_m.y, yp.x, s_c.x, left, ym.x, s_mm.x);
-            o.y = canon_cell(b_m.y, m_m, 1, s_m.z, yp.y, s_c.y, s_m.x, ym.y, s_mm.y);
-            o.z = canon_cell(b_m.z, m_m, 2, s_m.w, yp.z, s_c.z, s_m.y, ym.z, s_mm.z);
-            o.w = canon_cell(b_m.w, m_m, 3, right, yp.w, s_c.w, s_m.z, ym.w, s_mm.w);
+            float4 n;
+            n.x = canon_num(b_m.x, s_m.y, yp.x, s_c.x, left, ym.x, s_mm.x);
+            n.y = canon_num(b_m.y, s_m.z, yp.y, s_c.y, s_m.x, ym.y, s_mm.y);
+            n.z = canon_num(b_m.z, s_m.w, yp.z, s_c.z, s_m.y, ym.z, s_mm.z);
+            n.w = canon_num(b_m.w, right, yp.w, s_c.w, s_m.z, ym.w, s_mm.w);
+            float4 o = canon_div4(n, m_m, c.divtab);
             o.x = mask_is_water(m_m, 0) ? o.x : s_m.x;
             o.y = mask_is_water(m_m, 1) ? o.y : s_m.y;
             o.z = mask_is_water(m_m, 2) ? o.z : s_m.z;
@@ -285,6 +350,15 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
     c.xe = c.lane == 0 ? c.x0 - 1 : c.x0 + 4;
 
+    {   // DivEntry table (before the first barrier of the march, which orders it with its readers)
+        FLUID_LDS float* tab = c.lds + 2 * 2 * R * RW;  // DivEntry {a, r} pairs
+        c.divtab = (const FLUID_LDS char*)tab;
+        if (threadIdx.x < DIV_TABLE_ENTRIES) {
+            const float a = (float)threadIdx.x;
+            tab[2 * threadIdx.x] = a;
+            tab[2 * threadIdx.x + 1] = threadIdx.x == 0 ? 0.0f : 1.0f / a;  // RN(1/a): IEEE division
+        }
+    }
     // pad cells of every LDS row: x = -1 and x = NT*256 read as p_oob (outside the grid)
     for (int i = threadIdx.x; i < 2 * 2 * R * 2 * FUSED_PAD; i += FUSED_THREADS) {
         const int side = i % (2 * FUSED_PAD), row = i / (2 * FUSED_PAD);
