@@ -51,6 +51,21 @@ def parse_args():
     return ap.parse_args()
 
 
+def recorded_traffic(kernel, size):
+    """HBM bytes per launch of `kernel` from the PMC passes kept under profiles/ (rocprofv3 --pmc cannot
+    run inside this process): (bytes, source) for this kernel and grid, else (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic_*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel") == kernel and list(rec.get("grid", [])) == list(size):
+            return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def grid_dims(grid):
     if len(grid) == 1:
         return grid[0], grid[0], grid[0]
@@ -266,6 +281,8 @@ def main():
     launch_ms = loop_ms / sweeps * sweeps_per_launch
     kernel_ms = loop_ms / sweeps  # per sweep
     achieved = JACOBI_BYTES_PER_CELL * cells * sweeps_per_launch / (launch_ms * 1e-3) / 1e9
+    kernel_name = ("k12_canon2" if fused else "k12_canon") if w % 4 == 0 else "k12_plain"
+    traffic, traffic_source = recorded_traffic(kernel_name, size)
     out = {
         "metric": "pressure_jacobi_iterations_per_sec",
         "value": sweeps / wall,
@@ -278,8 +295,9 @@ def main():
                                f"{args.iters} Jacobi iterations per step (+ the two pressure clears)",
                    "grid": [w, h, d], "jacobi_iterations": args.iters, "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("k12_canon2" if fused else "k12_canon") if w % 4 == 0 else "k12_plain",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_source,
+                     "kernel": kernel_name,
                      "sweeps_per_launch": sweeps_per_launch,
                      "launch_ms": launch_ms, "ms_per_sweep": kernel_ms,
                      "algorithmic_bytes_per_launch":
