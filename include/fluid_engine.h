@@ -390,9 +390,20 @@ typedef enum fluid_option {
                                    /* grouped passes (default; every image ends the step with the   */
                                    /* bits the section list leaves, intermediates are not stored),  */
                                    /* 1 = the section list, one kernel per section                  */
+    FLUID_OPT_QUIET_BRICKS = 3,    /* fluid_run_step with grouped passes: 0 = 07+08, 09+10+11 and 13     */
+                                   /* skip bricks of 256x4x16 cells that have had no water in or   */
+                                   /* next to them for three steps — a step changes nothing there  */
+                                   /* (default); 1 = process every cell                             */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
+
+/* Diagnostics (synchronises the stream). */
+typedef enum fluid_stat {
+    FLUID_STAT_BRICKS = 0,       /* activity bricks of this context (256 x 4 x 16 cells each)          */
+    FLUID_STAT_QUIET_BRICKS = 1  /* bricks the last fluid_run_step skipped in 07+08, 09+10+11 and 13   */
+} fluid_stat;
+int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 
 #ifdef __cplusplus
 }

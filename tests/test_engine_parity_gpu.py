@@ -618,3 +618,36 @@ def test_pressure_division_special_values(iters):
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="special values: ")
     got = np.array([st.pressures_1[c] for c in cells[:7 * len(specials)]])
     assert np.isnan(got).any() and np.isinf(got).any() and (got == 0).any()
+
+
+@pytest.mark.parametrize("quiet", [0, 1])
+def test_full_step_quiet_bricks_match_oracle(quiet):
+    """Ten dam-break steps on a grid with room around the water: from the third step on fluid_run_step
+    skips the bricks far from the water in 07+08, 09+10+11 and 13 (quiet_bricks.h).  Every image equals
+    the oracle's after every step; the same with the skipping turned off."""
+    size = (64, 64, 96)
+    p, cap = dam_break_params(*size)
+    iters = 6
+    st = OracleState(p, cap, iters)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.set_option(E.OPT_QUIET_BRICKS, quiet)
+        eng.run_init()
+        st.run_init()
+        skipped = []
+        for k in range(10):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"quiet={quiet} step {k}: ")
+            skipped.append(eng.get_stat(E.STAT_QUIET_BRICKS))
+        total = eng.get_stat(E.STAT_BRICKS)
+        if quiet == 0:
+            assert skipped[0] == 0 and skipped[1] == 0           # streaks build up first
+            assert 0.3 * total < skipped[-1] < total             # most of this grid is far from the water
+        else:
+            assert skipped[-1] == 0
+        # a write from outside resets the streaks: the next step processes everything
+        eng.upload_image(E.VELOCITIES_1, st.velocities_1)
+        eng.run_step()
+        st.run_step()
+        assert_state_equal(eng, st, ctx=f"quiet={quiet} after upload: ")
+        assert eng.get_stat(E.STAT_QUIET_BRICKS) == 0

@@ -83,9 +83,12 @@ struct fluid_ctx {
     // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
+    uint64_t quiet_offset = 0;    // one byte per brick: steps since water was near (quiet_bricks.h)
+    bool quiet_valid = false;     // the streaks describe the images (nothing wrote them from outside)
+    bool quiet_in_use = false;    // inside fluid_run_step, between 06 and 13: kernels may skip
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
     uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter,
-                                          // [2] bricks holding water
+                                          // [2..6] brick summary, [8] quiet bricks of the last step
     uint32_t* brick_count_host = nullptr; // pinned, 5 words (k12_count_bricks); written by an async
                                           // copy after k12_prepare
     bool v1_w_zero = false;               // every texel of VELOCITIES_1 has w == +0.0f (kernels_step_fused.h)
@@ -139,6 +142,9 @@ struct fluid_ctx {
         return reinterpret_cast<float*>(arena + work_offset[i]) + LOOP_GHOST * g.plane;
     }
     uint8_t* bricks() const { return arena + active_offset; }
+    uint8_t* quiet() const { return arena + quiet_offset; }
+    // pointer for the kernels that may skip quiet bricks (null: process everything)
+    const uint8_t* quiet_or_null() const { return quiet_in_use ? quiet() : nullptr; }
     uint32_t* flags() const { return reinterpret_cast<uint32_t*>(arena + flags_offset); }
     Leaver* leavers() const { return reinterpret_cast<Leaver*>(arena + leavers_offset); }
     // bookkeeping for the fast path: call whenever an image's device contents change
@@ -154,6 +160,7 @@ struct fluid_ctx {
     }
     uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
     void params_changed() {
+        quiet_valid = false;
         mask_valid = rhs_valid = false;
         bg_valid[0] = bg_valid[1] = bg_valid[2] = false;
     }
@@ -230,7 +237,7 @@ ParamsK make_params_k(const fluid_params& p) {
 struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
-    uint64_t mask_offset, rhs_offset, active_offset, active_bytes, work_offset[3];
+    uint64_t mask_offset, rhs_offset, active_offset, active_bytes, quiet_offset, work_offset[3];
     uint64_t flags_offset, leavers_offset;
     uint32_t leavers_capacity;
     uint64_t total;
@@ -268,6 +275,8 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
         k12_brick_dims((int)p.fluid_size[0], (int)p.fluid_size[1], (int)dl, nbx, nby, nbz);
         L.active_bytes = (uint64_t)nbx * nby * nbz;
     }
+    off = align_up(off + L.active_bytes, kAlign);
+    L.quiet_offset = off;
     off = align_up(off + L.active_bytes, kAlign);
     for (int i = 0; i < 3; i++) {
         L.work_offset[i] = off;
@@ -425,18 +434,22 @@ bool fast_loop_possible(const fluid_ctx* c) {
 float oob_value(const fluid_ctx* c) {
     return (c->pk.t_solid == 0 || c->pk.t_water == 0) ? 0.0f : c->pk.p_air;
 }
-// mask, b_i and activity bricks, rebuilt only when CELL_TYPES / DIVERGENCES / parameters changed
-int ensure_prepared(fluid_ctx* c) {
-    if (c->mask_valid && c->rhs_valid) return FLUID_OK;
+// mask, b_i and activity bricks, rebuilt only when CELL_TYPES / DIVERGENCES / parameters changed.
+// `mask_only`: leave b_i for later (fluid_run_step builds the mask right after 06, before DIVERGENCES
+// of this step exists, because the quiet-brick map needs the activity bricks).
+int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
+    const bool want_rhs = !mask_only && !c->rhs_valid;
+    if (c->mask_valid && !want_rhs) return FLUID_OK;
     const GridK& g = c->g;
     const bool rebuilt_mask = !c->mask_valid;
     if (rebuilt_mask) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), g, c->pk, !c->mask_valid, !c->rhs_valid);
+                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs);
     HIP_TRY(c, hipGetLastError());
-    c->mask_valid = c->rhs_valid = true;
+    c->mask_valid = true;
+    if (want_rhs) c->rhs_valid = true;
     if (c->brick_count_host && rebuilt_mask) {
         k12_launch_count_bricks(c->stream, c->bricks(), g, c->flags() + 2);
         HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 20, hipMemcpyDeviceToHost,
@@ -661,6 +674,8 @@ int run_section_impl(fluid_ctx* c, int section) {
     float4* V2 = c->plane0<float4>(FLUID_IMG_VELOCITIES_2);
     uint32_t* dens = c->plane0<uint32_t>(FLUID_IMG_PARTICLE_DENSITIES_IMG);
     const unsigned pblocks = (unsigned)((c->particle_capacity + 255) / 256);
+    BrickK bk;  // activity / quiet bricks (quiet_bricks.h)
+    k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
 
     switch (section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
@@ -716,13 +731,13 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case STEP_0708_ADVECT_FORCES:
             hipLaunchKernelGGL(k07_advect<true>, grid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags());
+                               c->flags(), c->quiet_or_null(), bk);
             break;
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
             c->v1_w_zero = false;
             hipLaunchKernelGGL(k091011_solids_divergence, grid, block, 0, c->stream, T, V2, V1,
-                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk);
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk, c->quiet_or_null(), bk);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
@@ -733,7 +748,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             return FLUID_OK;
         case FLUID_SEC_07_ADVECT:
             hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags());
+                               c->flags(), (const uint8_t*)nullptr, bk);
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
@@ -769,7 +784,8 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_13_FIX_DIVERGENCE:
             hipLaunchKernelGGL(k13_fix_divergence, grid, block, 0, c->stream, T,
-                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk);
+                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk, c->quiet_or_null(),
+                               bk);
             c->v1_w_zero = true;
             break;
         case FLUID_SEC_14_PARTICLES:
@@ -948,6 +964,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->rhs_offset = L.rhs_offset;
     c->active_offset = L.active_offset;
     c->active_bytes = L.active_bytes;
+    c->quiet_offset = L.quiet_offset;
     for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
     c->flags_offset = L.flags_offset;
     c->leavers_offset = L.leavers_offset;
@@ -1040,6 +1057,7 @@ int fluid_buffer_bytes(const fluid_ctx* c, int buffer_id, uint64_t* bytes) {
 }
 
 int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t bytes) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
@@ -1140,6 +1158,7 @@ int fluid_set_pressure_iterations(fluid_ctx* c, uint32_t iterations) {
 }
 
 int fluid_set_diffuse_mode(fluid_ctx* c, int mode) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (mode != FLUID_DIFFUSE_REFERENCE_EXACT && mode != FLUID_DIFFUSE_INTENDED)
         return c->fail(FLUID_ERR_INVALID_ARG, "unknown diffuse mode %d", mode);
@@ -1148,6 +1167,7 @@ int fluid_set_diffuse_mode(fluid_ctx* c, int mode) {
 }
 
 int fluid_set_option(fluid_ctx* c, int option, int64_t value) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (option < 0 || option >= FLUID_OPT_COUNT)
         return c->fail(FLUID_ERR_INVALID_ARG, "unknown option %d", option);
@@ -1156,12 +1176,14 @@ int fluid_set_option(fluid_ctx* c, int option, int64_t value) {
 }
 
 int fluid_run_section(fluid_ctx* c, int section_id) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     return timed_section(c, section_id);
 }
 
 int fluid_clear_image(fluid_ctx* c, int image_id, const uint32_t value_bits[4]) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
@@ -1319,6 +1341,7 @@ int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
 }
 
 int fluid_run_init(fluid_ctx* c) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     static const int order[] = {FLUID_SEC_INIT_CLEAR_VELOCITIES_1, FLUID_SEC_INIT_CLEAR_CELL_TYPES,
@@ -1333,11 +1356,33 @@ int fluid_run_init(fluid_ctx* c) {
 // Entries [first, first + count) of SimulationStepSections (fluid_flow_sections.h:163-338; the ids are
 // consecutive in list order).  `grouped`: sections 04+05, 07+08 and 09+10+11 run as the grouped passes
 // of kernels_step_fused.h, each timed under the id of the section it stands in for.
-static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped) {
+static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool whole_step = false) {
     const bool group = grouped && c->g.W % 4 == 0;
     const int end = first + count;
+    // quiet bricks (quiet_bricks.h): only inside a whole grouped step on a whole-grid context whose
+    // pressure loop runs on the working buffers (that is where the activity bricks come from)
+    const bool quiet = whole_step && group && !c->is_slab && fast_loop_possible(c) &&
+                       c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT &&
+                       c->opt[FLUID_OPT_QUIET_BRICKS] == 0;
+    c->quiet_in_use = false;
     for (int s = first; s < end;) {
         int rc, used = 1;
+        if (quiet && s == FLUID_SEC_07_ADVECT) {
+            // CELL_TYPES of this step is final (06): activity bricks now, then the streaks
+            rc = ensure_prepared(c, true);
+            if (rc) return rc;
+            if (!c->quiet_valid)
+                HIP_TRY(c, hipMemsetAsync(c->quiet(), 0, c->active_bytes, c->stream));
+            BrickK bk;
+            k12_brick_dims(c->g.W, c->g.H, c->g.Dl, bk.nbx, bk.nby, bk.nbz);
+            const int nb = (int)c->active_bytes;
+            HIP_TRY(c, hipMemsetAsync(c->flags() + 8, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_update_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
+                               c->bricks(), c->quiet(), bk, c->flags() + 8);
+            HIP_TRY(c, hipGetLastError());
+            c->quiet_valid = true;
+            c->quiet_in_use = true;
+        }
         if (group && s == FLUID_SEC_04_COMPUTE_EXTRAPOLATED_VELOCITIES && end - s >= 2 &&
             c->v1_w_zero) {  // the pair of type scans needs w == 0 in all of VELOCITIES_1
             rc = timed_section(c, s, STEP_0405_EXTRAPOLATE);
@@ -1356,9 +1401,14 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped) {
         } else {
             rc = timed_section(c, s);
         }
-        if (rc) return rc;
+        if (rc) {
+            c->quiet_in_use = false;
+            return rc;
+        }
+        if (s == FLUID_SEC_13_FIX_DIVERGENCE) c->quiet_in_use = false;
         s += used;
     }
+    c->quiet_in_use = false;
     return FLUID_OK;
 }
 
@@ -1368,10 +1418,11 @@ int fluid_run_step(fluid_ctx* c) {
     if (c->is_slab) return slab_unsupported(c, "fluid_run_step");
     return run_step_slice(c, FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES,
                           FLUID_SEC_14_PARTICLES - FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES + 1,
-                          c->opt[FLUID_OPT_STEP_FUSION] == 0);
+                          c->opt[FLUID_OPT_STEP_FUSION] == 0, true);
 }
 
 int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (first_section_id < FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES ||
@@ -1447,6 +1498,7 @@ int fluid_image_plane_ptr(fluid_ctx* c, int image_id, int32_t plane, void** devi
 }
 
 int fluid_notify_image_written(fluid_ctx* c, int image_id) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
@@ -1455,6 +1507,7 @@ int fluid_notify_image_written(fluid_ctx* c, int image_id) {
 }
 
 int fluid_notify_ghost_planes_written(fluid_ctx* c, int image_id) {
+    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
@@ -1462,6 +1515,28 @@ int fluid_notify_ghost_planes_written(fluid_ctx* c, int image_id) {
     c->touched(image_id);
     c->v1_w_zero = w0;
     return FLUID_OK;
+}
+
+int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!value) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    switch (stat) {
+        case FLUID_STAT_BRICKS:
+            *value = c->active_bytes;
+            return FLUID_OK;
+        case FLUID_STAT_QUIET_BRICKS: {
+            uint32_t v = 0;
+            if (c->quiet_valid) {
+                HIP_TRY(c, hipMemcpyAsync(&v, c->flags() + 8, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+            *value = v;
+            return FLUID_OK;
+        }
+        default:
+            return c->fail(FLUID_ERR_INVALID_ARG, "unknown statistic %d", stat);
+    }
 }
 
 int fluid_slab_status(fluid_ctx* c, uint32_t* halo_violation) {

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "device_common.h"
+#include "quiet_bricks.h"
 
 namespace fluid {
 
@@ -268,7 +269,9 @@ __global__ void k11_divergence(const float4* __restrict__ v1, float* __restrict_
 
 // 13_fix_divergence/fix_divergence.comp:41-72
 __global__ void k13_fix_divergence(const uint8_t* __restrict__ t, const float* __restrict__ pr,
-                                   float4* __restrict__ v1, GridK g, ParamsK p) {
+                                   float4* __restrict__ v1, GridK g, ParamsK p,
+                                   const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk)  // quiet_bricks.h
     FLUID_CELL_THREAD();
     const uint32_t lt = t[id];  // :62
     const float lp = pr[id];    // :63

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "device_common.h"
+#include "quiet_bricks.h"
 
 namespace fluid {
 
@@ -92,7 +93,9 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
 template <bool FORCES>
 __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                            float4* __restrict__ v2, GridK g, ParamsK p,
-                           uint32_t* __restrict__ violation) {
+                           uint32_t* __restrict__ violation, const uint8_t* __restrict__ quiet,
+                           BrickK bk) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk)  // quiet_bricks.h
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lz = blockIdx.z;

@@ -26,8 +26,32 @@
 #pragma once
 
 #include "device_common.h"
+#include "quiet_bricks.h"
 
 namespace fluid {
+
+// ---- quiet bricks (quiet_bricks.h) ----------------------------------------------------------------
+__global__ void k_update_quiet(const uint8_t* __restrict__ active, uint8_t* __restrict__ streak,
+                               BrickK bk, uint32_t* __restrict__ quiet_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = bk.nbx * bk.nby * bk.nbz;
+    if (i >= n) return;
+    const int bx = i % bk.nbx, by = (i / bk.nbx) % bk.nby, bz = i / (bk.nbx * bk.nby);
+    uint32_t any = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                if ((unsigned)x < (unsigned)bk.nbx && (unsigned)y < (unsigned)bk.nby &&
+                    (unsigned)z < (unsigned)bk.nbz)
+                    any |= active[brick_index(bk, x, y, z)];
+            }
+    const uint32_t s = streak[i];
+    const uint32_t now = any ? 0u : (s < 255u ? s + 1u : 255u);
+    streak[i] = (uint8_t)now;
+    if (now >= QUIET_MIN_STREAK) atomicAdd(quiet_count, 1u);  // FLUID_STAT_QUIET_BRICKS
+}
+
 
 // ---- 04 + 05 ------------------------------------------------------------------------------------------
 // Per-component state of 05 (extrapolate_velocities.comp:48-56) for the four cells x..x+3 of a row:
@@ -150,7 +174,9 @@ __device__ __forceinline__ float solids_component(float v, bool cell_solid, bool
 
 __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
                                           const float4* __restrict__ v2, float4* __restrict__ v1,
-                                          float* __restrict__ div, GridK g, ParamsK p) {
+                                          float* __restrict__ div, GridK g, ParamsK p,
+                                          const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk)
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     const int lz = blockIdx.z;

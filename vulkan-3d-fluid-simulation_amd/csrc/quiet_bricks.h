@@ -1,0 +1,31 @@
+// quiet_bricks.h — skipping the parts of the grid where a step changes nothing.
+#pragma once
+
+#include "device_common.h"
+#include "pressure_common.h"  // the activity bricks (BrickK, BRICK_*)
+
+namespace fluid {
+
+// Far from the water a step changes nothing: 05 / 07 / 08 / 13 act only on cells that are, or touch,
+// water or air cells, and 10 is idempotent, so from the third consecutive step in which no water cell
+// lies within two cells of a brick, VELOCITIES_1 == VELOCITIES_2 (xyz) there, w = 0, and DIVERGENCES is
+// what 11 would store again.  fluid_run_step keeps, per activity brick (256 x 4 x 16 cells, the bricks
+// of the pressure loop), the number of consecutive steps in which neither the brick nor any of its 26
+// neighbours held water (k_update_quiet, from the map k12_prepare builds right after 06), and the
+// workgroups of 07+08, 09+10+11 and 13 whose cells lie in a brick with a streak >= QUIET_MIN_STREAK leave
+// at once.  Images keep the bits the full passes would have written (inside the step, VELOCITIES_1.w of
+// such a brick is 0 where the list has 1 between 10 and 13 — nobody reads it there).  Any write from
+// outside fluid_run_step (uploads, clears, single sections, parameters) resets the streaks.
+constexpr uint32_t QUIET_MIN_STREAK = 3;
+
+
+// for kernels launched with cell_grid() / cell_block() (64 x 4 x 1 cells per workgroup): one brick per
+// workgroup, a scalar test
+#define FLUID_LEAVE_IF_QUIET(quiet, bk)                                                          \
+    if (quiet) {                                                                                 \
+        const int qb_ = brick_index(bk, (int)(blockIdx.x * 64u) / BRICK_X,                       \
+                                    (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z); \
+        if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                    \
+    }
+
+}  // namespace fluid

@@ -48,6 +48,8 @@ DIFFUSE_REFERENCE_EXACT, DIFFUSE_INTENDED = 0, 1
 OPT_PRESSURE_KERNEL = 0
 OPT_JACOBI_FUSE = 1
 OPT_STEP_FUSION = 2
+OPT_QUIET_BRICKS = 3
+STAT_BRICKS, STAT_QUIET_BRICKS = 0, 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
     0, -1, -2, -3, -4, -5, -6)
@@ -62,7 +64,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
-    "fluid_notify_ghost_planes_written",
+    "fluid_notify_ghost_planes_written", "fluid_get_stat",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
     "fluid_pressure_loop_advance_part",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
@@ -138,6 +140,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
         "fluid_notify_ghost_planes_written": (C.c_int, [vp, C.c_int]),
+        "fluid_get_stat": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
         "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
@@ -421,6 +424,11 @@ class FluidEngine:
 
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))
+
+    def get_stat(self, stat: int) -> int:
+        v = C.c_uint64(0)
+        self._check(self._lib.fluid_get_stat(self._h, stat, C.byref(v)))
+        return int(v.value)
 
     def notify_ghost_planes_written(self, image_id: int):
         self._check(self._lib.fluid_notify_ghost_planes_written(self._h, image_id))
