@@ -446,7 +446,7 @@ int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs);
+                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs, c->quiet_or_null());
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = true;
     if (want_rhs) c->rhs_valid = true;
@@ -488,7 +488,7 @@ int import_pressures(fluid_ctx* c, int image, int w) {
             n++;
         }
     k12_launch_import_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
-                         c->work0(w), others[0], others[1], c->g, c->pk);
+                         c->work0(w), others[0], others[1], c->g, c->pk, c->quiet_or_null());
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[0] = c->bg_valid[1] = c->bg_valid[2] = true;
     return FLUID_OK;
@@ -772,11 +772,15 @@ int run_section_impl(fluid_ctx* c, int section) {
                                c->plane0<float>(FLUID_IMG_DIVERGENCES), g);
             break;
         case FLUID_SEC_12A_CLEAR_PRESSURES_1:
+        case FLUID_SEC_12B_CLEAR_PRESSURES_2: {
             c->pressure_dispatch_index = 0;
-            return fill_image(c, FLUID_IMG_PRESSURES_1, f32_bits(pk.p_air));
-        case FLUID_SEC_12B_CLEAR_PRESSURES_2:
-            c->pressure_dispatch_index = 0;
-            return fill_image(c, FLUID_IMG_PRESSURES_2, f32_bits(pk.p_air));
+            const int img = section == FLUID_SEC_12A_CLEAR_PRESSURES_1 ? FLUID_IMG_PRESSURES_1
+                                                                       : FLUID_IMG_PRESSURES_2;
+            if (!c->quiet_in_use) return fill_image(c, img, f32_bits(pk.p_air));
+            hipLaunchKernelGGL(k_fill_f32_unless_quiet, cell4_grid(g), block, 0, c->stream,
+                               c->plane0<float>(img), pk.p_air, g, c->quiet(), bk);
+            break;
+        }
         case FLUID_SEC_12_SOLVE_PRESSURE: {
             const uint32_t even = (c->pressure_dispatch_index % 2u) == 0u ? 1u : 0u;
             c->pressure_dispatch_index++;

@@ -28,6 +28,17 @@ __global__ void k_fill_u8_tail(uint8_t* __restrict__ dst, int64_t begin, int64_t
     if (i < end) dst[i] = v;
 }
 
+// The pressure clears inside fluid_run_step: R32F fill that leaves quiet bricks alone (quiet_bricks.h),
+// four cells per thread, launched with cell4_grid() / cell_block().
+__global__ void k_fill_f32_unless_quiet(float* __restrict__ dst, float v, GridK g,
+                                        const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.W || y >= g.H) return;
+    *reinterpret_cast<float4*>(dst + cidx(g, x, y, (int)blockIdx.z)) = make_float4(v, v, v, v);
+}
+
 // 02_update_water/update_water.comp:23-33
 __global__ void k02_update_water(const uint32_t* __restrict__ dens, uint8_t* __restrict__ newT,
                                  GridK g, ParamsK p) {

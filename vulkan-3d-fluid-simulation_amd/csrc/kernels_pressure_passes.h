@@ -6,6 +6,7 @@
 #pragma once
 
 #include "pressure_common.h"
+#include "quiet_bricks.h"
 
 namespace fluid {
 
@@ -26,7 +27,8 @@ __device__ __forceinline__ uint32_t byte_at(uint32_t w, int i) { return (w >> (8
 __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __restrict__ div,
                                uint8_t* __restrict__ mask, float* __restrict__ rhs,
                                uint8_t* __restrict__ active, BrickK bk, GridK g, ParamsK p,
-                               int do_mask, int do_rhs) {
+                               int do_mask, int do_rhs, const uint8_t* __restrict__ quiet) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // b_i-only passes of fluid_run_step (quiet_bricks.h)
     FLUID_V4_THREAD();
     const int lz = blockIdx.z;
     const int64_t id = cidx(g, x, y, lz);
@@ -73,7 +75,9 @@ __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __res
 // constants of the other two working buffers (their water cells are written by the sweeps)
 __global__ void k12_import_v4(const uint8_t* __restrict__ t, const float* __restrict__ pimg,
                               float* __restrict__ w0, float* __restrict__ w1,
-                              float* __restrict__ w2, GridK g, ParamsK p) {
+                              float* __restrict__ w2, GridK g, ParamsK p,
+                              const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // quiet_bricks.h: the constants are in place already
     FLUID_V4_THREAD();
     const int64_t id = cidx(g, x, y, (int)blockIdx.z);
     const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);

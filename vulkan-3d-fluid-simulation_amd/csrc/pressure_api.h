@@ -33,9 +33,10 @@ void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8
 // fluid_size.x % 4 == 0 (pressure_passes.hip)
 void k12_launch_prepare_v4(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask,
                            float* rhs, uint8_t* bricks, const GridK& g, const ParamsK& p,
-                           bool do_mask, bool do_rhs);
+                           bool do_mask, bool do_rhs, const uint8_t* quiet = nullptr);
 void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, float* w0, float* w1,
-                          float* w2, const GridK& g, const ParamsK& p);
+                          float* w2, const GridK& g, const ParamsK& p, const uint8_t* quiet = nullptr);
+// `quiet`: per-brick streaks (quiet_bricks.h) — workgroups in a quiet brick leave at once; null = all
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
                           float* p1, float* p2, const GridK& g, const ParamsK& p);
 // out[0..4] = {bricks with water, y brick range lo, hi, z brick range lo, hi}

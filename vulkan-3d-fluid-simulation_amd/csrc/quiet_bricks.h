@@ -13,7 +13,9 @@ namespace fluid {
 // of the pressure loop), the number of consecutive steps in which neither the brick nor any of its 26
 // neighbours held water (k_update_quiet, from the map k12_prepare builds right after 06), and the
 // workgroups of 07+08, 09+10+11 and 13 whose cells lie in a brick with a streak >= QUIET_MIN_STREAK leave
-// at once.  Images keep the bits the full passes would have written (inside the step, VELOCITIES_1.w of
+// at once; so do the pressure clears 12a / 12b (the loop writes water cells only, the rest still holds
+// p_air), the b_i pass and the import pass of the pressure loop (DIVERGENCES and the cell types of such
+// a brick have not changed since those passes last ran on it).  Images keep the bits the full passes would have written (inside the step, VELOCITIES_1.w of
 // such a brick is 0 where the list has 1 between 10 and 13 — nobody reads it there).  Any write from
 // outside fluid_run_step (uploads, clears, single sections, parameters) resets the streaks.
 constexpr uint32_t QUIET_MIN_STREAK = 3;
@@ -26,6 +28,14 @@ constexpr uint32_t QUIET_MIN_STREAK = 3;
         const int qb_ = brick_index(bk, (int)(blockIdx.x * 64u) / BRICK_X,                       \
                                     (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z); \
         if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                    \
+    }
+
+// the same for the four-cells-per-thread passes (64 x 4 threads = 256 x 4 x 1 cells per workgroup)
+#define FLUID_LEAVE_IF_QUIET_V4(quiet, bk)                                                         \
+    if (quiet) {                                                                                   \
+        const int qb_ = brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X,                        \
+                                    (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z);  \
+        if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                      \
     }
 
 }  // namespace fluid
