@@ -26,7 +26,7 @@ static int pick_zchunk(int row_groups, int depth, int cus) {
     const double startup = 3.0;
     double best_cost = 1e300;
     int best = std::min(depth, 32);
-    for (int zc = std::min(depth, row_groups * (depth / 16) >= cus ? 16 : 6); zc <= std::min(depth, 128);
+    for (int zc = std::min(depth, row_groups * (depth / 16) >= cus ? 16 : 2); zc <= std::min(depth, 128);
          zc++) {
         const int nz = (depth + zc - 1) / zc;
         std::vector<double> busy(cus, 0.0);  // min-heap by finish time
