@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--no-fuse", action="store_true", help="one dispatch per sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
-    ap.add_argument("--full-step-steps", type=int, default=3)
+    ap.add_argument("--full-step-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -110,22 +110,29 @@ def cpu_baseline_jacobi(size, iters_hint):
 def full_step_bench(size, iters, steps, device):
     """Full simulation steps/sec (01a…14) on the dam-break scene, single GPU."""
     import fluid_amd
+    from fluid_amd import engine as E
 
     p, cap = fluid_amd.dam_break_params(*size)
     with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters,
                                device=device) as eng:
         eng.run_init()
-        for _ in range(2):
+        for _ in range(4):  # the simulation's steady state: bricks far from the water have gone quiet
             eng.run_step()
         eng.sync()
-        eng.enable_timing(True)
-        eng.reset_timing()
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.run_step()
         eng.sync()
         dt = time.perf_counter() - t0
-        sections = {k: round(v[0] / steps, 4) for k, v in eng.section_times().items() if v[1]}
+        quiet = eng.get_stat(E.STAT_QUIET_BRICKS) / max(eng.get_stat(E.STAT_BRICKS), 1)
+        # per-section HIP-event times from a few more steps (not part of the rate above)
+        eng.enable_timing(True)
+        eng.reset_timing()
+        tsteps = min(steps, 3)
+        for _ in range(tsteps):
+            eng.run_step()
+        eng.sync()
+        sections = {k: round(v[0] / tsteps, 4) for k, v in eng.section_times().items() if v[1]}
     cells = size[0] * size[1] * size[2]
     step_bytes = (293.0 + 13.0 * iters) * cells + 48.0 * cap   # SURVEY.md §8d, reference layout
     return {
@@ -135,7 +142,10 @@ def full_step_bench(size, iters, steps, device):
         "steps": steps,
         "algorithmic_GBps": step_bytes * steps / dt / 1e9,
         "frac_of_hbm_peak": step_bytes * steps / dt / 1e9 / HBM_PEAK_GBS,
+        "quiet_brick_fraction": round(quiet, 4),
         "section_ms_per_step": sections,
+        "note": ("grouped passes: 04/05 = the two type scans of 04+05, 07 = 07+08, 09 = 09+10+11; "
+                 "12_solve_pressure includes its prepare / import / export passes"),
     }
 
 
@@ -151,6 +161,7 @@ def slab_full_step_bench(size, iters, steps, dist_ctx):
     sim.run_init()
     for _ in range(2):
         sim.run_step()
+    steps = min(steps, 5)
     sim.compute.sync()
     dist.barrier()
     t0 = time.perf_counter()
