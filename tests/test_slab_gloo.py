@@ -88,6 +88,9 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
         assert solver.overlapped > 0  # the split-pass schedule ran
     else:
         assert solver.overlapped == 0
+    # the measurement loop of bench.py --gpus N, including its inline-vs-overlapped probe
+    res = solver.benchmark(1, 0)
+    assert res["wall_s"] > 0 and res["halo_overlap"]["probed"] and "step_ms_inline" in res["halo_overlap"]
     if rank == 0:
         np.savez(os.path.join(out_dir, "result.npz"), a1=a1, a2=a2, b1=b1, b2=b2)
     dist.barrier()

@@ -620,6 +620,7 @@ class SlabPressureSolver:
         import torch
         import torch.distributed as dist
 
+        probe = self._probe_overlap()
         for _ in range(warmup):
             self.step()
         eng = getattr(self.compute, "engine", None)
@@ -639,7 +640,8 @@ class SlabPressureSolver:
         t = torch.tensor([wall], dtype=torch.float64, device=self.ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out = {"wall_s": float(t.item()),
-               "local_cells": self.size[0] * self.size[1] * self.z_count}
+               "local_cells": self.size[0] * self.size[1] * self.z_count,
+               "halo_overlap": probe}
         if eng is not None:
             ms, calls = eng.section_time_ms("12_solve_pressure")
             eng.enable_timing(False)
@@ -649,6 +651,33 @@ class SlabPressureSolver:
             out["exchange_ms_per_sweep"] = max(
                 0.0, 1e3 * out["wall_s"] / (steps * self.iterations) - out["kernel_ms_per_sweep"])
         return out
+
+    def _probe_overlap(self) -> dict:
+        """Untimed, before the warm-up: one step of the loop with the exchanges issued in line and one
+        with the split-pass overlap (solve()), each after a step of its own to set up streams and
+        communicators; every rank adopts the faster schedule (MAX over ranks).  Whether hiding an
+        8-MiB exchange is worth two extra launches per exchange depends on the link, so it is measured
+        where it runs."""
+        import torch
+        import torch.distributed as dist
+
+        if not self.overlap or self.ctx.world == 1 or "FLUID_SLAB_OVERLAP" in os.environ:
+            return {"used": bool(self.overlap and self.ctx.world > 1), "probed": False}
+        times = {}
+        for mode in (False, True):
+            self.overlap = mode
+            self.step()
+            self.compute.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            self.step()
+            self.compute.sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times[mode] = float(t.item())
+        self.overlap = times[True] < times[False]
+        return {"used": self.overlap, "probed": True, "step_ms_inline": 1e3 * times[False],
+                "step_ms_overlapped": 1e3 * times[True]}
 
     def gather_pressures(self):
         """Rank 0 gets the global PRESSURES_1 / PRESSURES_2 arrays (tests)."""
@@ -677,7 +706,8 @@ class SlabSimulation:
     (checked every step)."""
 
     def __init__(self, params: FluidParams, particle_capacity: int, iterations: int, ctx: DistContext,
-                 compute=None, transport: str = "direct", halo_depth: int = 8, grouped: bool = True):
+                 compute=None, transport: str = "direct", halo_depth: int = 8, grouped: bool = True,
+                 overlap: Optional[bool] = None):
         # grouped: 04+05, 07+08 and 09+10+11 as single passes (include/fluid_engine.h:
         # fluid_run_section_group); 09+10+11 needs fluid_size.x % 4 == 0
         self.grouped = grouped
@@ -692,6 +722,8 @@ class SlabSimulation:
                                                  pressure_iterations=iterations)
         self.pressure = SlabPressureSolver(self.size, iterations, ctx, self.compute, slab,
                                            transport=transport, halo_depth=halo_depth)
+        if overlap is not None:  # else SlabPressureSolver's default (FLUID_SLAB_OVERLAP)
+            self.pressure.overlap = overlap
         self.transport = transport
         self.ghost = min(self.compute.IMAGE_GHOST, min(n for _, n in partition_z(self.size[2],
                                                                                   ctx.world)))
