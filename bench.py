@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--no-fuse", action="store_true", help="one dispatch per sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
-    ap.add_argument("--full-step-steps", type=int, default=10)
+    ap.add_argument("--full-step-steps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -104,7 +104,82 @@ def cpu_baseline_jacobi(size, iters_hint):
                   f"({dt:.1f} s, {cells_per_s / 1e6:.1f} Mcells/s), scaled by cell count to "
                   f"{w}x{h}x{d}",
         "cells_per_s": cells_per_s,
+        "full_step_c1": cpu_vs_gpu_full_step_c1(),
     }
+
+
+def cpu_vs_gpu_full_step_c1():
+    """BASELINE.json configs[0] (64^3, 8 particles/cell, 40 Jacobi iterations, dam break): whole steps
+    of the single-threaded oracle and of the engine on the same scene."""
+    import fluid_amd
+    from oracle_binding import OracleState
+
+    size, iters, steps = (64, 64, 64), 40, 3
+    p, cap = fluid_amd.dam_break_params(*size)
+    st = OracleState(p, cap, iters)
+    st.run_init()
+    st.run_step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.run_step()
+    cpu_dt = (time.perf_counter() - t0) / steps
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.run_init()
+        for _ in range(4):
+            eng.run_step()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            eng.run_step()
+        eng.sync()
+        gpu_dt = (time.perf_counter() - t0) / 50
+    return {"workload": f"dam-break 64x64x64, {cap} particles, {iters} Jacobi iters",
+            "cpu_steps_per_sec": 1.0 / cpu_dt, "cpu_cores": 1, "gpu_steps_per_sec": 1.0 / gpu_dt}
+
+
+def measured_copy_bandwidth(device_index):
+    """Secondary roofline denominator: a 1-GiB device-to-device copy (hipMemcpyAsync),
+    read + write bytes per second, best of a few.  Uses the HIP runtime the engine library already
+    loaded (a second runtime in the process would not see the GPU)."""
+    import ctypes as C
+
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    hip = C.CDLL(path or "libamdhip64.so")
+    vp = C.c_void_p
+
+    def ok(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: hipError {rc}")
+
+    ok(hip.hipSetDevice(C.c_int(device_index)), "hipSetDevice")
+    nbytes = 1 << 30
+    src, dst, e0, e1 = vp(), vp(), vp(), vp()
+    ok(hip.hipMalloc(C.byref(src), C.c_size_t(nbytes)), "hipMalloc")
+    ok(hip.hipMalloc(C.byref(dst), C.c_size_t(nbytes)), "hipMalloc")
+    try:
+        ok(hip.hipMemsetAsync(src, C.c_int(1), C.c_size_t(nbytes), vp(0)), "hipMemsetAsync")
+        ok(hip.hipEventCreate(C.byref(e0)), "hipEventCreate")
+        ok(hip.hipEventCreate(C.byref(e1)), "hipEventCreate")
+        best = 0.0
+        for _ in range(6):
+            ok(hip.hipEventRecord(e0, vp(0)), "hipEventRecord")
+            ok(hip.hipMemcpyAsync(dst, src, C.c_size_t(nbytes), C.c_int(3), vp(0)), "hipMemcpyAsync")
+            ok(hip.hipEventRecord(e1, vp(0)), "hipEventRecord")
+            ok(hip.hipEventSynchronize(e1), "hipEventSynchronize")
+            ms = C.c_float(0)
+            ok(hip.hipEventElapsedTime(C.byref(ms), e0, e1), "hipEventElapsedTime")
+            best = max(best, 2.0 * nbytes / (ms.value * 1e-3) / 1e9)
+        hip.hipEventDestroy(e0)
+        hip.hipEventDestroy(e1)
+    finally:
+        hip.hipFree(src)
+        hip.hipFree(dst)
+    return best
 
 
 def full_step_bench(size, iters, steps, device):
@@ -116,8 +191,8 @@ def full_step_bench(size, iters, steps, device):
     with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters,
                                device=device) as eng:
         eng.run_init()
-        for _ in range(4):  # the simulation's steady state: bricks far from the water have gone quiet
-            eng.run_step()
+        for _ in range(10):  # ten warm-up steps (the simulation's steady state: bricks far
+            eng.run_step()   # from the water have gone quiet)
         eng.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -322,6 +397,12 @@ def main():
         "clears_ms_per_step": clear_ms / args.steps,
         "cells_per_sec": cells * sweeps / wall,
     }
+    try:
+        out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(local_rank)
+        out["roofline"]["frac_of_measured_copy"] = achieved / out["roofline"]["measured_copy_GBps"]
+    except Exception as exc:  # secondary figure only
+        out["roofline"]["measured_copy_GBps"] = None
+        out["roofline"]["measured_copy_error"] = f"{type(exc).__name__}: {exc}"
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_jacobi(size, args.iters)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
