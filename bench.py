@@ -356,6 +356,9 @@ def main():
         eng.section_time_ms("12b_clear_pressures_2")[0]
     eng.enable_timing(False)
     # parity spot check of what was just timed would need the full-size oracle; tests cover it.
+    # Convergence read-out of the iterate the loop left (after the timed region)
+    res_max, res_sumsq, res_cells = eng.pressure_residual(E.PRESSURES_1 if args.iters % 2 == 0
+                                                          else E.PRESSURES_2)
     eng.close()
 
     cells = w * h * d
@@ -394,6 +397,11 @@ def main():
                               "streaming the grid once, so the algorithmic 13 B/cell/sweep figure "
                               "can exceed the HBM roofline (SURVEY.md §8d allows this); measured "
                               "HBM traffic per launch is in profiles/") if fused else ""},
+        "residual_after_loop": {"max_abs": res_max,
+                                "rms": (res_sumsq / max(res_cells, 1)) ** 0.5,
+                                "water_cells": res_cells,
+                                "note": "r = b - sum(neighbours) + aii*p of the last iterate "
+                                        "(fluid_pressure_residual; not in the reference)"},
         "clears_ms_per_step": clear_ms / args.steps,
         "cells_per_sec": cells * sweeps / wall,
     }

@@ -398,6 +398,17 @@ typedef enum fluid_option {
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
 
+/* Convergence read-out of the pressure solve (not in the reference, which never looks at its
+ * residual; synchronises the stream).  For every WATER cell of this context, in the sweep's own fp32
+ * arithmetic: s = b_i - sum over non-solid neighbours of (water ? P[nb] : pressure_air)
+ * (pressure.comp:54-61), r = s + aii * P[cell] — the sweep stores -s / aii, so r = 0 at its fixed
+ * point.  *max_abs = max |r| (exact; NaN residuals are ignored), *sum_squares = sum of r^2 in double
+ * (accumulation order unspecified), *water_cells = number of cells.  `image_id` = FLUID_IMG_PRESSURES_1
+ * or _2.  On a Z-slab context the figures cover the slab (its ghost planes must be current); combine
+ * them across ranks with max / sum.  Reduced per wavefront with wave64 shuffles, one atomic each. */
+int fluid_pressure_residual(fluid_ctx* ctx, int image_id, float* max_abs, double* sum_squares,
+                            uint64_t* water_cells);
+
 /* Diagnostics (synchronises the stream). */
 typedef enum fluid_stat {
     FLUID_STAT_BRICKS = 0,       /* activity bricks of this context (256 x 4 x 16 cells each)          */

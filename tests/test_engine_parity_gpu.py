@@ -651,3 +651,48 @@ def test_full_step_quiet_bricks_match_oracle(quiet):
         st.run_step()
         assert_state_equal(eng, st, ctx=f"quiet={quiet} after upload: ")
         assert eng.get_stat(E.STAT_QUIET_BRICKS) == 0
+
+
+def _numpy_residual(st, pimg):
+    """r = s + aii * P per WATER cell in fp32, pressure.comp:54-61 order (include/fluid_engine.h:
+    fluid_pressure_residual)."""
+    p = st.params
+    f = np.float32
+    t = st.cell_types
+    d, h, w = t.shape
+    tp = np.zeros((d + 2, h + 2, w + 2), np.uint8)       # out of bounds reads as type 0
+    tp[1:-1, 1:-1, 1:-1] = t
+    pp = np.zeros((d + 2, h + 2, w + 2), f)
+    pp[1:-1, 1:-1, 1:-1] = pimg
+    s = ((st.divergences * f(p.fluid_density)) * f(p.cell_width)) / f(p.time_delta)
+    aii = np.zeros(t.shape, np.int32)
+    for dz, dy, dx in [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 0, -1), (0, -1, 0), (-1, 0, 0)]:
+        ty = tp[1 + dz:1 + dz + d, 1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+        q = pp[1 + dz:1 + dz + d, 1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+        live = ty != p.cell_type_solid
+        contrib = np.where(ty == p.cell_type_water, q, f(p.pressure_air)).astype(f)
+        s = np.where(live, (s - contrib).astype(f), s).astype(f)
+        aii += live
+    r = (s + (aii.astype(f) * pimg).astype(f)).astype(f)
+    return r[t == p.cell_type_water]
+
+
+@pytest.mark.parametrize("size", [(24, 20, 16), (64, 9, 7), (17, 13, 9)])
+def test_pressure_residual_readout(size):
+    st = random_state(size, seed=13, iters=30)
+    with make_engine(st) as eng, np.errstate(all="ignore"):
+        for img, field in ((E.PRESSURES_1, "pressures_1"), (E.PRESSURES_2, "pressures_2")):
+            r = _numpy_residual(st, getattr(st, field))
+            mx, ss, n = eng.pressure_residual(img)
+            assert n == r.size and n > 0
+            assert np.float32(mx).view(np.uint32) == np.abs(r).max().view(np.uint32)   # exact
+            assert abs(ss - float(np.sum(r.astype(np.float64) ** 2))) <= 1e-9 * ss
+        before = eng.pressure_residual(E.PRESSURES_2)[0]
+        eng.solve_pressure(30)   # Jacobi on a diagonally dominant system: the residual shrinks
+        st.solve_pressure(30)
+        after = eng.pressure_residual(E.PRESSURES_2)[0]
+        r = _numpy_residual(st, st.pressures_2)
+        assert np.float32(after).view(np.uint32) == np.abs(r).max().view(np.uint32)
+        assert after < before
+        with pytest.raises(fluid_amd.FluidEngineError, match="not a pressure image"):
+            eng.pressure_residual(E.DIVERGENCES)

@@ -1521,6 +1521,32 @@ int fluid_notify_ghost_planes_written(fluid_ctx* c, int image_id) {
     return FLUID_OK;
 }
 
+int fluid_pressure_residual(fluid_ctx* c, int image_id, float* max_abs, double* sum_squares,
+                            uint64_t* water_cells) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (image_id != FLUID_IMG_PRESSURES_1 && image_id != FLUID_IMG_PRESSURES_2)
+        return c->fail(FLUID_ERR_INVALID_ARG, "image %d is not a pressure image", image_id);
+    HIP_TRY(c, hipSetDevice(c->device));
+    struct {
+        uint32_t max_bits, pad;
+        double sum_sq;
+        unsigned long long cells;
+    } host;
+    static_assert(sizeof host == 24, "ResidualOut layout");
+    void* dev = c->flags() + 16;  // 8-byte aligned scratch inside the flags block
+    HIP_TRY(c, hipMemsetAsync(dev, 0, 32, c->stream));
+    k12_launch_residual(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
+                        c->plane0<float>(FLUID_IMG_DIVERGENCES), c->plane0<float>(image_id), c->g,
+                        c->pk, dev);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&host, dev, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (max_abs) memcpy(max_abs, &host.max_bits, 4);
+    if (sum_squares) *sum_squares = host.sum_sq;
+    if (water_cells) *water_cells = host.cells;
+    return FLUID_OK;
+}
+
 int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!value) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");

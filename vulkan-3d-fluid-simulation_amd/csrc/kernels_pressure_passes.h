@@ -121,4 +121,69 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
     if (w_odd) put(w_odd, p2);
 }
 
+// ---- convergence read-out (not in the reference, which never looks at its residual) -----------------
+// Residual of the sweep's linear system at a WATER cell, in the sweep's own fp32 arithmetic:
+//     s = b_i - sum over non-solid neighbours of (water ? P[nb] : p_air)      (pressure.comp:54-61)
+//     r = s + aii * P[cell]            (the sweep stores P' = -s / aii, so r = 0 at its fixed point)
+// Per-wavefront reduction with wave64 shuffles, then one atomic per wavefront: max |r| as the bit
+// pattern of a non-negative float (monotonic as an unsigned integer), sum of r^2 and the number of
+// water cells in double / 64-bit.  NaN residuals are ignored by the maximum and poison the sum.
+struct ResidualOut {
+    unsigned int max_abs_bits;
+    unsigned int pad;
+    double sum_sq;
+    unsigned long long water_cells;
+};
+
+__global__ void k12_residual(const uint8_t* __restrict__ t, const float* __restrict__ div,
+                             const float* __restrict__ pimg, GridK g, ParamsK p,
+                             ResidualOut* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    float r_abs = 0.0f;
+    double r_sq = 0.0;
+    unsigned int wet = 0;
+    if (x < g.W && y < g.H) {
+        const int64_t id = cidx(g, x, y, lz);
+        if ((uint32_t)t[id] == p.t_water) {
+            int aii = 0;
+            float s = ((div[id] * p.rho) * p.dx) / p.dt;
+            auto nb = [&](uint32_t ty, float q) {
+                if (ty != p.t_solid) {
+                    s = s - (ty == p.t_water ? q : p.p_air);
+                    aii++;
+                }
+            };
+            const uint32_t txp = type_at(t, g, x + 1, y, lz), typ = type_at(t, g, x, y + 1, lz);
+            const uint32_t tzp = t[cidx(g, x, y, lz + 1)];
+            const uint32_t txm = type_at(t, g, x - 1, y, lz), tym = type_at(t, g, x, y - 1, lz);
+            const uint32_t tzm = t[cidx(g, x, y, lz - 1)];
+            nb(txp, txp == p.t_water ? f32_at(pimg, g, x + 1, y, lz) : 0.f);
+            nb(typ, typ == p.t_water ? f32_at(pimg, g, x, y + 1, lz) : 0.f);
+            nb(tzp, tzp == p.t_water ? pimg[cidx(g, x, y, lz + 1)] : 0.f);
+            nb(txm, txm == p.t_water ? f32_at(pimg, g, x - 1, y, lz) : 0.f);
+            nb(tym, tym == p.t_water ? f32_at(pimg, g, x, y - 1, lz) : 0.f);
+            nb(tzm, tzm == p.t_water ? pimg[cidx(g, x, y, lz - 1)] : 0.f);
+            const float ap = (float)aii * pimg[id];
+            const float r = s + ap;
+            r_abs = fabsf(r);
+            r_sq = (double)r * (double)r;
+            wet = 1;
+        }
+    }
+    // wave64 butterfly: every lane ends with the wavefront's max / sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r_abs = fmaxf(r_abs, __shfl_xor(r_abs, off, 64));
+        r_sq += __shfl_xor(r_sq, off, 64);
+        wet += __shfl_xor(wet, off, 64);
+    }
+    if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && wet != 0) {
+        atomicMax(&out->max_abs_bits, __float_as_uint(r_abs));
+        atomicAdd(&out->sum_sq, r_sq);
+        atomicAdd(&out->water_cells, (unsigned long long)wet);
+    }
+}
+
 }  // namespace fluid

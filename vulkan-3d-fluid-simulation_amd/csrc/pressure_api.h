@@ -40,6 +40,9 @@ void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, fl
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
                           float* p1, float* p2, const GridK& g, const ParamsK& p);
 // out[0..4] = {bricks with water, y brick range lo, hi, z brick range lo, hi}
+// convergence read-out: out32 = 32 zeroed bytes {uint32 max|r| bits, pad, double sum r^2, uint64 water cells}
+void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
+                         const GridK& g, const ParamsK& p, void* out32);
 void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out);
 // Where the water is, in cells (whole bricks), as known to the host: rows [y_lo, y_hi) and local planes
 // [z_lo, z_hi) hold every brick with water; `fraction` of all bricks hold water.  valid = false: unknown

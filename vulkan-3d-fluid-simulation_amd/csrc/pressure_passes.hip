@@ -33,4 +33,10 @@ void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, 
                        p);
 }
 
+void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
+                         const GridK& g, const ParamsK& p, void* out32) {
+    hipLaunchKernelGGL(k12_residual, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.Dl), dim3(64, 4, 1), 0, s, t,
+                       div, pimg, g, p, static_cast<ResidualOut*>(out32));
+}
+
 }  // namespace fluid

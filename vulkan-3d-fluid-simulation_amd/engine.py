@@ -64,7 +64,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
-    "fluid_notify_ghost_planes_written", "fluid_get_stat",
+    "fluid_notify_ghost_planes_written", "fluid_get_stat", "fluid_pressure_residual",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
     "fluid_pressure_loop_advance_part",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
@@ -141,6 +141,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
         "fluid_notify_ghost_planes_written": (C.c_int, [vp, C.c_int]),
         "fluid_get_stat": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
+        "fluid_pressure_residual": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_uint64)]),
         "fluid_pressure_loop_begin": (C.c_int, [vp]),
         "fluid_pressure_loop_max_sweeps": (C.c_int, [vp]),
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
@@ -424,6 +426,13 @@ class FluidEngine:
 
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))
+
+    def pressure_residual(self, image_id: int = PRESSURES_2):
+        """(max |r|, sum r^2, water cells) of the pressure system for PRESSURES_1 / _2."""
+        m, s, n = C.c_float(0), C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.fluid_pressure_residual(self._h, image_id, C.byref(m), C.byref(s),
+                                                      C.byref(n)))
+        return float(m.value), float(s.value), int(n.value)
 
     def get_stat(self, stat: int) -> int:
         v = C.c_uint64(0)
