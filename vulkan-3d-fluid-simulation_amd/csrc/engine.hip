@@ -676,6 +676,9 @@ int run_section_impl(fluid_ctx* c, int section) {
     const unsigned pblocks = (unsigned)((c->particle_capacity + 255) / 256);
     BrickK bk;  // activity / quiet bricks (quiet_bricks.h)
     k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
+    // kernels that can skip quiet bricks: one workgroup per brick row while skipping is on
+    const int qchunks = c->quiet_in_use ? 4 : 1;
+    const dim3 qgrid((g.W + 64 * qchunks - 1) / (64 * qchunks), grid.y, grid.z);
 
     switch (section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
@@ -730,14 +733,15 @@ int run_section_impl(fluid_ctx* c, int section) {
             hipLaunchKernelGGL(k0405_apply, cell4_grid(g), block, 0, c->stream, T, newT, V2, V1, g, pk);
             break;
         case STEP_0708_ADVECT_FORCES:
-            hipLaunchKernelGGL(k07_advect<true>, grid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags(), c->quiet_or_null(), bk);
+            hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
+                               c->flags(), c->quiet_or_null(), bk, qchunks);
             break;
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
             c->v1_w_zero = false;
-            hipLaunchKernelGGL(k091011_solids_divergence, grid, block, 0, c->stream, T, V2, V1,
-                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk, c->quiet_or_null(), bk);
+            hipLaunchKernelGGL(k091011_solids_divergence, qgrid, block, 0, c->stream, T, V2, V1,
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk, c->quiet_or_null(), bk,
+                               qchunks);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
@@ -748,7 +752,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             return FLUID_OK;
         case FLUID_SEC_07_ADVECT:
             hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags(), (const uint8_t*)nullptr, bk);
+                               c->flags(), (const uint8_t*)nullptr, bk, 1);
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
@@ -787,9 +791,9 @@ int run_section_impl(fluid_ctx* c, int section) {
             return launch_pressure(c, even);
         }
         case FLUID_SEC_13_FIX_DIVERGENCE:
-            hipLaunchKernelGGL(k13_fix_divergence, grid, block, 0, c->stream, T,
+            hipLaunchKernelGGL(k13_fix_divergence, qgrid, block, 0, c->stream, T,
                                c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk, c->quiet_or_null(),
-                               bk);
+                               bk, qchunks);
             c->v1_w_zero = true;
             break;
         case FLUID_SEC_14_PARTICLES:

@@ -281,9 +281,11 @@ __global__ void k11_divergence(const float4* __restrict__ v1, float* __restrict_
 // 13_fix_divergence/fix_divergence.comp:41-72
 __global__ void k13_fix_divergence(const uint8_t* __restrict__ t, const float* __restrict__ pr,
                                    float4* __restrict__ v1, GridK g, ParamsK p,
-                                   const uint8_t* __restrict__ quiet, BrickK bk) {
-    FLUID_LEAVE_IF_QUIET(quiet, bk)  // quiet_bricks.h
-    FLUID_CELL_THREAD();
+                                   const uint8_t* __restrict__ quiet, BrickK bk, int xchunks) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)  // quiet_bricks.h
+    FLUID_FOR_CELLS_OF_ROW(xchunks)
+    const int64_t id = cidx(g, x, y, lz);
+    const int gz = g.z0 + lz;
     const uint32_t lt = t[id];  // :62
     const float lp = pr[id];    // :63
     const float k = (p.dt / p.rho) / p.dx;  // :71
@@ -304,6 +306,7 @@ __global__ void k13_fix_divergence(const uint8_t* __restrict__ t, const float* _
     q.z = q.z - k * dv[2];
     q.w = 0.0f;
     v1[id] = q;
+    FLUID_END_FOR_CELLS
 }
 
 }  // namespace fluid

@@ -94,12 +94,9 @@ template <bool FORCES>
 __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                            float4* __restrict__ v2, GridK g, ParamsK p,
                            uint32_t* __restrict__ violation, const uint8_t* __restrict__ quiet,
-                           BrickK bk) {
-    FLUID_LEAVE_IF_QUIET(quiet, bk)  // quiet_bricks.h
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int lz = blockIdx.z;
-    if (x >= g.W || y >= g.H) return;
+                           BrickK bk, int xchunks) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)  // quiet_bricks.h
+    FLUID_FOR_CELLS_OF_ROW(xchunks)
     const int gz = g.z0 + lz;
     const int64_t id = cidx(g, x, y, lz);
     const float4 cur = v1[id];                          // :87
@@ -125,6 +122,7 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
         }
     }
     v2[id] = o;  // :96
+    FLUID_END_FOR_CELLS
 }
 
 // 14_particles/particles.comp:45-51

@@ -175,12 +175,10 @@ __device__ __forceinline__ float solids_component(float v, bool cell_solid, bool
 __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
                                           const float4* __restrict__ v2, float4* __restrict__ v1,
                                           float* __restrict__ div, GridK g, ParamsK p,
-                                          const uint8_t* __restrict__ quiet, BrickK bk) {
-    FLUID_LEAVE_IF_QUIET(quiet, bk)
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int lz = blockIdx.z;
-    if (x >= g.W || y >= g.H) return;
+                                          const uint8_t* __restrict__ quiet, BrickK bk,
+                                          int xchunks) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)
+    FLUID_FOR_CELLS_OF_ROW(xchunks)
     const int64_t id = cidx(g, x, y, lz);
     const int gz = g.z0 + lz;
     const float r = p.repel;
@@ -206,6 +204,7 @@ __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
     d = d + az;
     d = d - vz;
     div[id] = d;
+    FLUID_END_FOR_CELLS
 }
 
 }  // namespace fluid

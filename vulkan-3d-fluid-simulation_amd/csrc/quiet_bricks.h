@@ -23,12 +23,25 @@ constexpr uint32_t QUIET_MIN_STREAK = 3;
 
 // for kernels launched with cell_grid() / cell_block() (64 x 4 x 1 cells per workgroup): one brick per
 // workgroup, a scalar test
-#define FLUID_LEAVE_IF_QUIET(quiet, bk)                                                          \
+// (x 4 cells with `xchunks` = 4: such launches give every workgroup four 64-cell chunks of a row to loop
+// over, i.e. one workgroup per brick row — a launch over mostly quiet bricks is bound by the rate at
+// which empty workgroups can be dispatched, about one per cycle)
+#define FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)                                                 \
     if (quiet) {                                                                                 \
-        const int qb_ = brick_index(bk, (int)(blockIdx.x * 64u) / BRICK_X,                       \
+        const int qb_ = brick_index(bk, (int)(blockIdx.x * 64u * (unsigned)(xchunks)) / BRICK_X, \
                                     (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z); \
         if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                    \
     }
+
+// cell loop of those kernels: x runs over the workgroup's `xchunks` chunks of 64 cells
+#define FLUID_FOR_CELLS_OF_ROW(xchunks)                                              \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;                             \
+    const int lz = blockIdx.z;                                                       \
+    if (y >= g.H) return;                                                            \
+    for (int xc_ = 0; xc_ < (xchunks); xc_++) {                                      \
+        const int x = ((int)blockIdx.x * (xchunks) + xc_) * 64 + (int)threadIdx.x;   \
+        if (x >= g.W) break;
+#define FLUID_END_FOR_CELLS }
 
 // the same for the four-cells-per-thread passes (64 x 4 threads = 256 x 4 x 1 cells per workgroup)
 #define FLUID_LEAVE_IF_QUIET_V4(quiet, bk)                                                         \
