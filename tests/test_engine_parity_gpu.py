@@ -696,3 +696,92 @@ def test_pressure_residual_readout(size):
         assert after < before
         with pytest.raises(fluid_amd.FluidEngineError, match="not a pressure image"):
             eng.pressure_residual(E.DIVERGENCES)
+
+
+def test_pressure_512cubed_default_equals_plain_and_window_matches_oracle():
+    """512^3 full-fluid grid (BASELINE config C4, the size the metric is quoted on), 6 sweeps: the
+    default path (two sweeps per pass, division-free quotient, chunked z march) agrees bit for bit with
+    the one-thread-per-cell kernel on the images everywhere, and a 20-plane window recomputed by the
+    oracle matches outside its dependence cone."""
+    n, iters = 512, 6
+    p = default_params(n, n, n, 0)
+    shape = (n, n, n)
+    t = scenes.full_fluid_types(shape)
+    div = scenes.full_fluid_divergence(shape)
+    sums = {}
+    keep = None
+    for variant in (1, 0):
+        with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
+            eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.upload_image(E.CELL_TYPES, t)
+            eng.upload_image(E.DIVERGENCES, div)
+            eng.run_section("12a_clear_pressures_1")
+            eng.run_section("12b_clear_pressures_2")
+            eng.solve_pressure(iters)
+            p1, p2 = eng.download_image(E.PRESSURES_1), eng.download_image(E.PRESSURES_2)
+        if keep is None:
+            keep = (p1, p2)
+        else:
+            assert_bit_equal(p1, keep[0], "512^3 P1 default vs plain")
+            assert_bit_equal(p2, keep[1], "512^3 P2 default vs plain")
+        sums[variant] = int(p1.view(np.uint32).astype(np.uint64).sum())
+    z0, zc = 300, 20
+    pw = default_params(n, n, zc, 0)
+    sw = OracleState(pw, 0, iters)
+    sw.cell_types[...] = t[z0:z0 + zc]
+    sw.divergences[...] = div[z0:z0 + zc]
+    sw.pressures_1[...] = 1.0
+    sw.pressures_2[...] = 1.0
+    sw.solve_pressure(iters)
+    lo, hi = iters, zc - iters
+    assert_bit_equal(keep[0][z0 + lo:z0 + hi], sw.pressures_1[lo:hi], "512^3 window P1")
+    assert_bit_equal(keep[1][z0 + lo:z0 + hi], sw.pressures_2[lo:hi], "512^3 window P2")
+
+
+def test_full_step_256cubed_grouped_and_quiet_equal_the_section_list():
+    """256^3 dam break (BASELINE config C3 shape), six whole steps: fluid_run_step with grouped passes,
+    quiet bricks and box-shaped launches against the plain section list (one kernel per section, every
+    cell processed) — two code paths through the engine, every image and the particles bit-identical."""
+    n, iters, steps = 256, 12, 6
+    p, cap = dam_break_params(n, n, n)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as a, \
+            fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as b:
+        b.set_option(E.OPT_STEP_FUSION, 1)
+        b.set_option(E.OPT_JACOBI_FUSE, 1)
+        a.run_init()
+        b.run_init()
+        for _ in range(steps):
+            a.run_step()
+            b.run_step()
+        assert a.get_stat(E.STAT_QUIET_BRICKS) > 0 and b.get_stat(E.STAT_QUIET_BRICKS) == 0
+        for name, img in IMAGE_FIELDS.items():
+            assert_bit_equal(a.download_image(img), b.download_image(img), f"256^3 {name}")
+        assert_bit_equal(a.download_particles(), b.download_particles(), "256^3 particles")
+
+
+@pytest.mark.parametrize("size,xr,iters", [((768, 12, 20), (256, 512), 16), ((1024, 10, 12), (256, 768), 17),
+                                            ((512, 9, 8), (0, 256), 16), ((512, 9, 8), (256, 512), 18),
+                                            ((1024, 6, 5), (512, 560), 16)])
+def test_pressure_fused_x_window_launches(size, xr, iters):
+    """Sparse scene whose water spans one or two 256-cell columns of a wider grid: the loop launches
+    the two-sweeps kernel over that x window only (FusedRange::xwin0); the cells next to the window —
+    air, solid and inactive ones, at the grid edge too — reach the kernel through the pad loads."""
+    w, h, d = size
+    st = random_state(size, seed=8, iters=iters)
+    rng = np.random.default_rng(3)
+    # no water outside [xr[0], xr[1]); everything else stays random (solids and air next to the window)
+    outside = np.ones(w, bool)
+    outside[xr[0]:xr[1]] = False
+    wet_outside = (st.cell_types == CELL_WATER) & outside[None, None, :]
+    st.cell_types[wet_outside] = rng.choice(np.array([CELL_AIR, CELL_SOLID], np.uint8),
+                                            size=int(wet_outside.sum()))
+    # water right up to both window edges in some rows
+    st.cell_types[2:d - 2, 2:h - 2, xr[0]] = CELL_WATER
+    st.cell_types[2:d - 2, 2:h - 2, xr[1] - 1] = CELL_WATER
+    if xr[0] == 0 or xr[1] == w:   # keep the domain faces solid, as a step would
+        st.cell_types[:, :, 0] = CELL_SOLID
+        st.cell_types[:, :, -1] = CELL_SOLID
+    with make_engine(st) as eng:
+        eng.solve_pressure(iters)
+        st.solve_pressure(iters)
+        assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx=f"x window {xr}: ")

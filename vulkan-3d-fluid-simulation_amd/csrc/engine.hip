@@ -88,8 +88,8 @@ struct fluid_ctx {
     bool quiet_in_use = false;    // inside fluid_run_step, between 06 and 13: kernels may skip
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
     uint64_t flags_offset = 0;            // [0] sampler halo violation, [1] leaver counter,
-                                          // [2..6] brick summary, [8] quiet bricks of the last step
-    uint32_t* brick_count_host = nullptr; // pinned, 5 words (k12_count_bricks); written by an async
+                                          // [2..8] brick summary, [9] quiet bricks of the last step, [10..11] x extent of the water
+    uint32_t* brick_count_host = nullptr; // pinned, 7 words (k12_count_bricks); written by an async
                                           // copy after k12_prepare
     bool v1_w_zero = false;               // every texel of VELOCITIES_1 has w == +0.0f (kernels_step_fused.h)
     bool box_pending = false;             // that copy has been enqueued and not been waited for
@@ -442,17 +442,21 @@ int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
     if (c->mask_valid && !want_rhs) return FLUID_OK;
     const GridK& g = c->g;
     const bool rebuilt_mask = !c->mask_valid;
-    if (rebuilt_mask) HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
+    if (rebuilt_mask) {
+        HIP_TRY(c, hipMemsetAsync(c->bricks(), 0, c->active_bytes, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->flags() + 10, 0, 8, c->stream));  // x extent of the water
+    }
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs, c->quiet_or_null());
+                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs, c->quiet_or_null(),
+                          c->flags() + 10);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = true;
     if (want_rhs) c->rhs_valid = true;
     if (c->brick_count_host && rebuilt_mask) {
-        k12_launch_count_bricks(c->stream, c->bricks(), g, c->flags() + 2);
-        HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 20, hipMemcpyDeviceToHost,
+        k12_launch_count_bricks(c->stream, c->bricks(), g, c->flags() + 2, c->flags() + 10);
+        HIP_TRY(c, hipMemcpyAsync(c->brick_count_host, c->flags() + 2, 28, hipMemcpyDeviceToHost,
                                   c->stream));
         c->box_pending = true;
         c->box.valid = false;  // fraction: the previous loop's, a hint until refresh_box()
@@ -474,6 +478,8 @@ int refresh_box(fluid_ctx* c) {
     c->box.y_hi = std::min((int)h[2] * by, c->g.H);
     c->box.z_lo = (int)h[3] * bz;
     c->box.z_hi = std::min((int)h[4] * bz, c->g.Dl);
+    c->box.x_lo = (int)h[5];  // cells
+    c->box.x_hi = std::min((int)h[6], c->g.W);
     return FLUID_OK;
 }
 // Import / background cover the owned planes; ghost planes of the working buffers are filled by the
@@ -1384,9 +1390,9 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
             BrickK bk;
             k12_brick_dims(c->g.W, c->g.H, c->g.Dl, bk.nbx, bk.nby, bk.nbz);
             const int nb = (int)c->active_bytes;
-            HIP_TRY(c, hipMemsetAsync(c->flags() + 8, 0, 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->flags() + 9, 0, 4, c->stream));
             hipLaunchKernelGGL(k_update_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
-                               c->bricks(), c->quiet(), bk, c->flags() + 8);
+                               c->bricks(), c->quiet(), bk, c->flags() + 9);
             HIP_TRY(c, hipGetLastError());
             c->quiet_valid = true;
             c->quiet_in_use = true;
@@ -1562,7 +1568,7 @@ int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
         case FLUID_STAT_QUIET_BRICKS: {
             uint32_t v = 0;
             if (c->quiet_valid) {
-                HIP_TRY(c, hipMemcpyAsync(&v, c->flags() + 8, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(&v, c->flags() + 9, 4, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
             }
             *value = v;

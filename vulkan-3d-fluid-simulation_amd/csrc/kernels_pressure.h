@@ -279,19 +279,23 @@ __global__ void k12_prepare(const uint8_t* __restrict__ t, const float* __restri
 }
 
 // Summary of the activity bricks for the host (one small workgroup): out[0] = bricks that hold water,
-// out[1..2] = [lo, hi) brick range in y that holds them, out[3..4] = the same in z (lo = hi = 0 when no
-// brick holds water).  The host shapes the launches of sparse scenes with it.
+// out[1..2] = [lo, hi) brick range in y that holds them, out[3..4] = the same in z, out[5..6] = the x
+// range of the water in cells (k12_prepare_v4's x_extent) (lo = hi = 0 when no brick holds water).  The host shapes the launches of sparse scenes with it.
 __global__ void k12_count_bricks(const uint8_t* __restrict__ active, BrickK bk,
-                                 uint32_t* __restrict__ out) {
-    __shared__ uint32_t sh[5];
-    if (threadIdx.x < 5) sh[threadIdx.x] = (threadIdx.x == 1 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;
+                                 uint32_t* __restrict__ out, const uint32_t* __restrict__ x_extent,
+                                 int width) {
+    __shared__ uint32_t sh[7];
+    if (threadIdx.x < 7) sh[threadIdx.x] = (threadIdx.x & 1u) ? 0xFFFFFFFFu : 0u;  // odd slots: minima
     __syncthreads();
     const int n = bk.nbx * bk.nby * bk.nbz;
-    uint32_t c = 0, ylo = 0xFFFFFFFFu, yhi = 0, zlo = 0xFFFFFFFFu, zhi = 0;
+    uint32_t c = 0, ylo = 0xFFFFFFFFu, yhi = 0, zlo = 0xFFFFFFFFu, zhi = 0, xlo = 0xFFFFFFFFu, xhi = 0;
     for (int i = threadIdx.x; i < n; i += 256)
         if (active[i]) {
             const uint32_t by = (uint32_t)((i / bk.nbx) % bk.nby), bz = (uint32_t)(i / (bk.nbx * bk.nby));
+            const uint32_t bx = (uint32_t)(i % bk.nbx);
             c++;
+            xlo = min(xlo, bx);
+            xhi = max(xhi, bx + 1u);
             ylo = min(ylo, by);
             yhi = max(yhi, by + 1u);
             zlo = min(zlo, bz);
@@ -303,10 +307,14 @@ __global__ void k12_count_bricks(const uint8_t* __restrict__ active, BrickK bk,
         atomicMax(&sh[2], yhi);
         atomicMin(&sh[3], zlo);
         atomicMax(&sh[4], zhi);
+        atomicMin(&sh[5], xlo);
+        atomicMax(&sh[6], xhi);
     }
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (threadIdx.x < 7) {
         uint32_t v = sh[threadIdx.x];
+        if (threadIdx.x == 5) v = (uint32_t)width - x_extent[0];  // cells, from the mask pass
+        if (threadIdx.x == 6) v = x_extent[1];
         if (sh[0] == 0u) v = 0u;
         out[threadIdx.x] = v;
     }

@@ -131,8 +131,13 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
 //                       planes near its faces and the planes in between in separate launches, so that
 //                       the halo exchange overlaps the larger one); nz_lo = z-chunks below the hole.
 //                       No hole: hole_lo = hole_hi = zout_hi, nz_lo = all chunks.
+//   xwin0               (k12_canon2<NT, true> only) global x of the workgroups' first cell: the launch
+//                       covers the window [xwin0, xwin0 + NT*256) of every row instead of the whole row.
+//                       Valid when every water cell of the grid lies inside the window: the columns
+//                       just outside it then hold non-water constants, the same in every iterate, which
+//                       the edge lanes load into the pad cells of the LDS rows.
 struct FusedRange {
-    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo;
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0;
 };
 
 // Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
@@ -141,9 +146,12 @@ struct FusedRange {
 //   s[4]  iterate j+1 : slots (i, i+1) = planes zc-2, zc-1; slot i+2 receives plane zc
 //   b[4], m[4]        : slots (i+1, i+2) = planes zc-1 (stage 2), zc (stage 1); slot i+3 receives zc+1
 //   h[2]  halo row    : slot i&1 = plane zc; the other receives plane zc+1   (halo wavefronts only)
+//   padv[4] (windowed launches) : iterate j at the column just outside the window, slots (i, i+1) =
+//                                  planes zc-1, zc; slot i+2 receives plane zc+1
 struct FusedState {
     float4 j[4], s[4], b[4], h[2];
     uint32_t m[4];
+    float padv[4];
 };
 
 template <int NT>
@@ -164,6 +172,11 @@ struct FusedCtx {
     int mlo, mhi;  // same for mask / b_i (one ghost plane per side)
     int lane, rr, x0, xe;
     unsigned boff, boff_h;
+    // windowed launches: byte offset of this lane's pad column (left for lanes < 32, right otherwise) in
+    // its row, whether that cell exists, whether this lane stores a pad cell and where (LDS x index)
+    unsigned boff_pad;
+    bool pad_in, pad_writer;
+    int pad_x;
     float p_oob;
     bool row_in, halo_in, halo_lo, halo_hi, is_out_row;
     bool wave_clean;     // every lane of this wavefront lies inside the grid (wave-uniform)
@@ -188,6 +201,9 @@ struct FusedCtx {
         const float4 pa4 = make_float4(p_oob, p_oob, p_oob, p_oob);
         return (ok && j_ok(lz)) ? v : pa4;
     }
+    __device__ __forceinline__ float fix_pad(float v, int lz) const {
+        return (pad_in && j_ok(lz)) ? v : p_oob;
+    }
     __device__ __forceinline__ uint32_t fix_m(uint32_t m, int lz) const {
         if (wave_clean && m_ok(lz)) return m;
         return m_ok(lz) ? ((m & lane_mask) | (MASK_DRY4 & ~lane_mask)) : MASK_DRY4;
@@ -195,7 +211,7 @@ struct FusedCtx {
 };
 
 // One plane step: I = ring phase (k mod 4), zc = plane of iterate j+1 formed in this step.
-template <int NT, int I>
+template <int NT, int I, bool WIN>
 __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st, int zc) {
     constexpr int R = FusedCtx<NT>::R;
     constexpr int buf = I & 1;
@@ -214,12 +230,22 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
     st.h[(I + 1) & 1] = ld_f4(c.pin + o1, c.boff_h);
     st.b[(I + 3) & 3] = ld_f4(c.rhs + a1, c.boff);
     st.m[(I + 3) & 3] = ld_u32(c.mask + a1, c.boff >> 2);
+    if (WIN)
+        st.padv[(I + 2) & 3] =
+            *reinterpret_cast<const float*>(reinterpret_cast<const char*>(c.pin + o1) + c.boff_pad);
 
     // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
     FLUID_LDS float* jrow = c.row_ptr(buf, 0, c.rr);
     FLUID_LDS float* srow = c.row_ptr(buf, 1, c.rr);
     lds_st4(jrow + c.x0, jc);
     lds_st4(srow + c.x0, s_m);
+    if (WIN) {
+        // the columns next to the window hold non-water constants: the same value in both iterates
+        if (c.pad_writer) {
+            jrow[c.pad_x] = c.fix_pad(st.padv[(I + 1) & 3], zc);
+            srow[c.pad_x] = c.fix_pad(st.padv[I & 3], zc - 1);
+        }
+    }
     __syncthreads();
 
     // ---- fix up what the previous step loaded (only wavefronts / planes on the grid boundary do
@@ -279,7 +305,7 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
     }
 }
 
-template <int NT>
+template <int NT, bool WIN>
 __global__ void __launch_bounds__(FUSED_THREADS)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
            const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pmid,
@@ -333,7 +359,8 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         if (any == 0) return;
     }
 
-    const bool xin = c.x0 < g.W;
+    const int gx0 = (WIN ? rg.xwin0 : 0) + c.x0;     // global x of this lane's first cell
+    const bool xin = gx0 < g.W;
     c.row_in = xin && (unsigned)y < (unsigned)g.H;   // this lane's cells exist
     c.is_out_row = c.rr >= 1 && c.rr <= R - 2 && c.row_in;
     c.halo_lo = c.rr == 0;
@@ -344,11 +371,21 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.wave_clean = __builtin_amdgcn_ballot_w64(!c.row_in || (is_halo && !c.halo_in)) == 0ull;
     c.lane_mask = c.row_in ? 0xFFFFFFFFu : 0u;
     // in-plane byte offsets (safe addresses for lanes / rows outside the grid)
-    const unsigned xs = xin ? (unsigned)c.x0 : 0u;
+    const unsigned xs = xin ? (unsigned)gx0 : 0u;
     c.boff = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
     c.boff_h = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)yh < (unsigned)g.H) ? yh : 0));
     // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
     c.xe = c.lane == 0 ? c.x0 - 1 : c.x0 + 4;
+    if (WIN) {
+        const int xl = rg.xwin0 - 1, xr = rg.xwin0 + NT * 256;  // the columns next to the window
+        const int gxp = c.lane < 32 ? xl : xr;
+        const bool col_in = (unsigned)gxp < (unsigned)g.W;
+        c.pad_in = col_in && (unsigned)y < (unsigned)g.H;
+        c.boff_pad = 4u * ((col_in ? (unsigned)gxp : 0u) +
+                           (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
+        c.pad_writer = (c.lane == 0 && tx == 0) || (c.lane == 63 && tx == NT - 1);
+        c.pad_x = c.lane == 0 ? -1 : NT * 256;
+    }
 
     {   // DivEntry table (before the first barrier of the march, which orders it with its readers)
         FLUID_LDS float* tab = c.lds + 2 * 2 * R * RW;  // DivEntry {a, r} pairs
@@ -380,16 +417,24 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     st.m[1] = MASK_DRY4;
     st.b[2] = ld_f4(rhs + c.m_off(zc), c.boff);
     st.m[2] = ld_u32(mask + c.m_off(zc), c.boff >> 2);
+    if (WIN) {
+        auto pad_at = [&](int lz) {
+            return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pin + c.j_off(lz)) +
+                                                   c.boff_pad);
+        };
+        st.padv[0] = pad_at(zc - 1);
+        st.padv[1] = pad_at(zc);
+    }
 
     const int steps = c.ze - c.zb + 2;  // iterate j+1 at planes zb-1 .. ze, iterate j+2 one behind
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step<NT, 0>(c, st, zc);
+        fused_step<NT, 0, WIN>(c, st, zc);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step<NT, 1>(c, st, zc + 1);
+        fused_step<NT, 1, WIN>(c, st, zc + 1);
         if (k + 2 >= steps) break;
-        fused_step<NT, 2>(c, st, zc + 2);
+        fused_step<NT, 2, WIN>(c, st, zc + 2);
         if (k + 3 >= steps) break;
-        fused_step<NT, 3>(c, st, zc + 3);
+        fused_step<NT, 3, WIN>(c, st, zc + 3);
     }
 }
 

@@ -27,7 +27,8 @@ __device__ __forceinline__ uint32_t byte_at(uint32_t w, int i) { return (w >> (8
 __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __restrict__ div,
                                uint8_t* __restrict__ mask, float* __restrict__ rhs,
                                uint8_t* __restrict__ active, BrickK bk, GridK g, ParamsK p,
-                               int do_mask, int do_rhs, const uint8_t* __restrict__ quiet) {
+                               int do_mask, int do_rhs, const uint8_t* __restrict__ quiet,
+                               uint32_t* __restrict__ x_extent) {
     FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // b_i-only passes of fluid_run_step (quiet_bricks.h)
     FLUID_V4_THREAD();
     const int lz = blockIdx.z;
@@ -68,6 +69,20 @@ __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __res
         *reinterpret_cast<uint32_t*>(mask + id) = out;
         // same value from every writer: a benign race (the array was zeroed before this launch)
         if (any_water) active[brick_index(bk, x / BRICK_X, y / BRICK_Y, lz / BRICK_Z)] = 1;
+        // x extent of the water, to 4 cells: x_extent[0] = max (W - x_lo), x_extent[1] = max x_hi (both
+        // zeroed before the launch); one pair of atomics per wavefront that holds water
+        const unsigned long long wet = __builtin_amdgcn_ballot_w64(any_water);
+        if (wet != 0ull) {
+            const int lane = (int)(threadIdx.x & 63u);
+            const int first = __builtin_ctzll(wet), last = 63 - __builtin_clzll(wet);
+            if (lane == first) {
+                // look before the atomic: after the first few wavefronts hardly any raises an extreme
+                // (a stale look only costs a redundant atomic)
+                const uint32_t lo = (uint32_t)(g.W - x), hi = (uint32_t)(x + 4 * (last - first) + 4);
+                if (lo > __atomic_load_n(&x_extent[0], __ATOMIC_RELAXED)) atomicMax(&x_extent[0], lo);
+                if (hi > __atomic_load_n(&x_extent[1], __ATOMIC_RELAXED)) atomicMax(&x_extent[1], hi);
+            }
+        }
     }
 }
 

@@ -33,22 +33,27 @@ void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8
 // fluid_size.x % 4 == 0 (pressure_passes.hip)
 void k12_launch_prepare_v4(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask,
                            float* rhs, uint8_t* bricks, const GridK& g, const ParamsK& p,
-                           bool do_mask, bool do_rhs, const uint8_t* quiet = nullptr);
+                           bool do_mask, bool do_rhs, const uint8_t* quiet, uint32_t* x_extent);
+// x_extent: two zeroed words; a mask pass leaves {W - (lowest x of a water cell, to 4 cells), highest
+// x + 1 (to 4 cells)} there (both 0: no water)
 void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, float* w0, float* w1,
                           float* w2, const GridK& g, const ParamsK& p, const uint8_t* quiet = nullptr);
 // `quiet`: per-brick streaks (quiet_bricks.h) — workgroups in a quiet brick leave at once; null = all
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
                           float* p1, float* p2, const GridK& g, const ParamsK& p);
-// out[0..4] = {bricks with water, y brick range lo, hi, z brick range lo, hi}
+// out[0..6] = {bricks with water, y brick range lo, hi, z brick range lo, hi, x CELL range lo, hi (from
+// the mask pass's x_extent)}
 // convergence read-out: out32 = 32 zeroed bytes {uint32 max|r| bits, pad, double sum r^2, uint64 water cells}
 void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
                          const GridK& g, const ParamsK& p, void* out32);
-void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out);
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out,
+                             const uint32_t* x_extent);
 // Where the water is, in cells (whole bricks), as known to the host: rows [y_lo, y_hi) and local planes
 // [z_lo, z_hi) hold every brick with water; `fraction` of all bricks hold water.  valid = false: unknown
 // (launch over the whole grid).
 struct ActiveBox {
     bool valid = false;
+    int x_lo = 0, x_hi = 0;  // cells (to 4), not bricks: an x window need not be brick-aligned
     int y_lo = 0, y_hi = 0, z_lo = 0, z_hi = 0;
     float fraction = -1.0f;
 };
@@ -70,5 +75,11 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
 // the output planes [part_lo, part_hi) (clipped to the pass's output range), FUSED_EDGES the rest
 enum { FUSED_WHOLE = 0, FUSED_EDGES = 1, FUSED_INTERIOR = 2 };
 bool k12_canon2_supports(const GridK& g);
+struct FusedRange;
+// the same over an x window of nt_window (1 or 2) 256-cell columns starting at rg.xwin0
+hipError_t k12_launch_canon2_win(hipStream_t s, int nt_window, const uint8_t* mask, const float* rhs,
+                                 const float* pin, float* pout, float* pmid, const uint8_t* bricks,
+                                 const GridK& g, float p_oob, const FusedRange& rg,
+                                 const ActiveBox& box, int part, int part_lo, int part_hi);
 
 }  // namespace fluid

@@ -1,131 +1,9 @@
 // pressure_fused.hip — translation unit of the two-sweeps-per-pass kernel (kernels_pressure_fused.h).
-#include "kernels_pressure_fused.h"
-#include "pressure_api.h"
-
-#include <algorithm>
-#include <cstdlib>
-#include <map>
-#include <tuple>
-#include <vector>
+#include "pressure_fused_launch.h"
 
 namespace fluid {
 
 bool k12_canon2_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 1024 && g.Dl >= 2; }
-
-// z-chunk choice.  One 16-wavefront workgroup occupies a CU, so a launch runs in "rounds" of one
-// workgroup per CU and a tile count just above a multiple of the CU count wastes most of a round.
-// Estimate the makespan of every candidate chunk length by dealing the tiles (cost = planes + 2
-// pipeline steps + a fixed start-up) to the CUs in launch order, and take the best.  Host
-// arithmetic, cached per geometry.
-static int pick_zchunk(int row_groups, int depth, int cus) {
-    // cached per geometry (a slab loop alternates between a few depths; the model costs ~1 ms)
-    static std::map<std::tuple<int, int, int>, int> cache;
-    const auto key = std::make_tuple(row_groups, depth, cus);
-    const auto hit = cache.find(key);
-    if (hit != cache.end()) return hit->second;
-    const double startup = 3.0;
-    double best_cost = 1e300;
-    int best = std::min(depth, 32);
-    for (int zc = std::min(depth, row_groups * (depth / 16) >= cus ? 16 : 2); zc <= std::min(depth, 128);
-         zc++) {
-        const int nz = (depth + zc - 1) / zc;
-        std::vector<double> busy(cus, 0.0);  // min-heap by finish time
-        auto cmp = [](double a, double b) { return a > b; };
-        std::make_heap(busy.begin(), busy.end(), cmp);
-        double makespan = 0.0;
-        for (int z = 0; z < nz; z++) {
-            const int planes = std::min(zc, depth - z * zc);
-            const double cost = planes + 2 + startup;
-            for (int y = 0; y < row_groups; y++) {
-                std::pop_heap(busy.begin(), busy.end(), cmp);
-                busy.back() += cost;
-                makespan = std::max(makespan, busy.back());
-                std::push_heap(busy.begin(), busy.end(), cmp);
-            }
-        }
-        if (makespan < best_cost) {
-            best_cost = makespan;
-            best = zc;
-        }
-    }
-    cache[key] = best;
-    return best;
-}
-
-static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            n <= 0)
-            n = 256;
-    }
-    return n;
-}
-
-template <int NT>
-static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
-                            float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
-                            float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
-                            int part_lo, int part_hi) {
-    static bool attr_set = false;  // per process and instantiation; the attribute is per function
-    const size_t lds = fused_lds_bytes(NT);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    constexpr int TY = FUSED_WAVES / NT - 2;
-    FusedRange r = rg;
-    int ty0 = 0, ty1 = (g.H + TY - 1) / TY;  // row tiles [ty0, ty1)
-    // Sparse scene on a whole-grid context: launch only the tiles whose output rows / planes meet the
-    // bricks that hold water.  The others would leave at once (no water cell to write), but a
-    // workgroup of 16 wavefronts that starts and leaves still costs a slot on a CU.
-    if (box.valid && rg.zout_lo == 0 && rg.zout_hi == g.Dl) {
-        if (box.y_hi <= box.y_lo || box.z_hi <= box.z_lo) return hipSuccess;  // no water at all
-        ty0 = box.y_lo / TY;
-        ty1 = (std::min(box.y_hi, g.H) + TY - 1) / TY;
-        r.zout_lo = std::max(0, box.z_lo);
-        r.zout_hi = std::min(g.Dl, box.z_hi);
-    }
-    r.ytile0 = ty0;
-    const int by = ty1 - ty0;
-    // planes to compute: [zout_lo, zout_hi) minus the hole [part_lo, part_hi) (part = edges), or only
-    // the hole (part = interior); whole pass otherwise
-    if (part != FUSED_WHOLE) {
-        const int a = std::min(std::max(part_lo, r.zout_lo), r.zout_hi);
-        const int b = std::min(std::max(part_hi, a), r.zout_hi);
-        if (part == FUSED_INTERIOR) {
-            r.zout_lo = a;
-            r.zout_hi = b;
-        } else {
-            r.hole_lo = a;
-            r.hole_hi = b;
-        }
-    }
-    if (part != FUSED_EDGES) r.hole_lo = r.hole_hi = r.zout_hi;
-    const int seg1 = r.hole_lo - r.zout_lo, seg2 = r.zout_hi - r.hole_hi;
-    const int depth = std::max(seg1, seg2);
-    if (depth <= 0) return hipSuccess;
-    int zchunk = std::min(pick_zchunk(by, depth, cu_count()), depth);
-    // Sparse scene without a box (Z slab: the ghost planes are not covered by the activity map): most
-    // workgroups leave at once and the few that work should be short, so that they run side by side.
-    if (!box.valid && box.fraction >= 0.f &&
-        box.fraction * by * ((depth + zchunk - 1) / zchunk) < 0.75f * cu_count())
-        zchunk = std::min(zchunk, 24);
-    if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
-    r.nz_lo = (seg1 + zchunk - 1) / zchunk;
-    const dim3 grid(1, by, r.nz_lo + (seg2 + zchunk - 1) / zchunk);
-    BrickK bk;
-    bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
-    bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
-    bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
-    hipLaunchKernelGGL(k12_canon2<NT>, grid, dim3(FUSED_THREADS), lds, s, mask, rhs, pin, pout, pmid,
-                       bricks, bk, g, p_oob, zchunk, r);
-    return hipSuccess;
-}
 
 hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                              float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
@@ -143,12 +21,24 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.ytile0 = 0;
     rg.hole_lo = rg.hole_hi = rg.zout_hi;
     rg.nz_lo = 0;
+    rg.xwin0 = 0;
     const int nt = (g.W + 255) / 256;
-    if (nt == 1) return launch_nt<1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    // Sparse scene, whole-grid context: if the bricks that hold water span one or two 256-cell columns of
+    // a wider grid, launch over that x window only (fewer lanes, more rows per workgroup).
+    if (box.valid && rg.zout_lo == 0 && rg.zout_hi == g.Dl && box.x_hi > box.x_lo) {
+        const int x0 = box.x_lo & ~31;  // 128-byte aligned rows
+        const int ntw = (box.x_hi - x0 + 255) / 256;
+        if ((ntw == 1 || ntw == 2) && ntw < nt) {
+            rg.xwin0 = x0;
+            return k12_launch_canon2_win(s, ntw, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box,
+                                         part, part_lo, part_hi);
+        }
+    }
+    if (nt == 1) return launch_nt<1, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
-    if (nt == 2) return launch_nt<2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    if (nt == 2) return launch_nt<2, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
-    if (nt <= 4) return launch_nt<4>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    if (nt <= 4) return launch_nt<4, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
     return hipErrorInvalidValue;
 }

@@ -12,11 +12,11 @@ static dim3 v4_grid(const GridK& g, int planes) {
 
 void k12_launch_prepare_v4(hipStream_t s, const uint8_t* t, const float* div, uint8_t* mask,
                            float* rhs, uint8_t* bricks, const GridK& g, const ParamsK& p,
-                           bool do_mask, bool do_rhs, const uint8_t* quiet) {
+                           bool do_mask, bool do_rhs, const uint8_t* quiet, uint32_t* x_extent) {
     BrickK bk;
     k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
     hipLaunchKernelGGL(k12_prepare_v4, v4_grid(g, g.Dl), v4_block(), 0, s, t, div, mask, rhs, bricks,
-                       bk, g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0, do_mask ? nullptr : quiet);
+                       bk, g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0, do_mask ? nullptr : quiet, x_extent);
 }
 
 void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, float* w0, float* w1,

@@ -62,10 +62,11 @@ void k12_launch_prepare(hipStream_t s, const uint8_t* t, const float* div, uint8
                        bricks, bricks_of(g), g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0);
 }
 
-void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out) {
+void k12_launch_count_bricks(hipStream_t s, const uint8_t* bricks, const GridK& g, uint32_t* out,
+                             const uint32_t* x_extent) {
     BrickK bk;
     k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
-    hipLaunchKernelGGL(k12_count_bricks, dim3(1), dim3(256), 0, s, bricks, bk, out);
+    hipLaunchKernelGGL(k12_count_bricks, dim3(1), dim3(256), 0, s, bricks, bk, out, x_extent, g.W);
 }
 
 void k12_launch_import(hipStream_t s, const uint8_t* t, const float* pimg, float* work,
