@@ -12,9 +12,42 @@ namespace fluid {
 // CLAMP_TO_EDGE (fluid_flow_sections.h:95; advect.comp:52-56).  Same fp32 definition as the oracle
 // (oracle/fluid_oracle.c: axis_taps): s = coord/n; u = s*n; ub = u - 0.5; i0 = floor(ub);
 // a = ub - i0; i1 = i0 + 1; indices clamped to [0, n-1].
-__device__ __forceinline__ void axis_taps(float coord, int n, int& i0, int& i1, float& a) {
-    const float fn = (float)n;
-    const float s = coord / fn;
+// extent of one axis with what the division by it needs, built once per thread (make_axes)
+struct AxisN {
+    int n;
+    float fn, inv;  // inv = 1 / n, exact when pow2
+    bool pow2;
+};
+struct Axes {
+    AxisN x, y, z;
+};
+__device__ __forceinline__ AxisN make_axis(int n) {
+    AxisN a;
+    a.n = n;
+    a.fn = (float)n;
+    a.pow2 = (n & (n - 1)) == 0;
+    a.inv = 1.0f / a.fn;
+    return a;
+}
+__device__ __forceinline__ Axes make_axes(const GridK& g) {
+    Axes a;
+    a.x = make_axis(g.W);
+    a.y = make_axis(g.H);
+    a.z = make_axis(g.Dg);
+    return a;
+}
+__device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0, int& i1, float& a) {
+    const int n = ax.n;
+    const float fn = ax.fn;
+    // coord / n.  For n a power of two the quotient is coord * 2^-k, exactly the same correctly rounded
+    // value (one rounding of the same real number, subnormal results included), without the ~11
+    // instructions of an IEEE division; 12 samples x 3 axes per advected cell make that worth a
+    // wave-uniform branch.
+    float s;
+    if (ax.pow2)
+        s = coord * ax.inv;
+    else
+        s = coord / fn;
     const float u = s * fn;
     const float ub = u - 0.5f;
     float fl = floorf(ub);
@@ -34,15 +67,16 @@ __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f
 // of an RGBA32F image; z taps are global indices converted to local planes (whole-grid contexts
 // have z0 = 0).  The eight taps are scalar loads of one channel of the texel.
 template <int COMP>
-__device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const GridK& g, float px,
-                                             float py, float pz, uint32_t* __restrict__ violation) {
+__device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const GridK& g,
+                                             const Axes& axes, float px, float py, float pz,
+                                             uint32_t* __restrict__ violation) {
     const float mx = COMP == 0 ? 0.5f : 0.0f, my = COMP == 1 ? 0.5f : 0.0f,
                 mz = COMP == 2 ? 0.5f : 0.0f;
     int x0, x1, y0, y1, z0, z1;
     float ax, ay, az;
-    axis_taps(px + mx, g.W, x0, x1, ax);
-    axis_taps(py + my, g.H, y0, y1, ay);
-    axis_taps(pz + mz, g.Dg, z0, z1, az);
+    axis_taps(px + mx, axes.x, x0, x1, ax);
+    axis_taps(py + my, axes.y, y0, y1, ay);
+    axis_taps(pz + mz, axes.z, z0, z1, az);
     z0 -= g.z0;
     z1 -= g.z0;
     {   // Z-slab contexts hold IMG_GHOST planes of the neighbouring slabs: a tap beyond them cannot be
@@ -68,7 +102,8 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
 template <int COMP>
 __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
                                                   const float4* __restrict__ v1, const GridK& g,
-                                                  const ParamsK& p, int x, int y, int lz, int gz,
+                                                  const Axes& axes, const ParamsK& p, int x, int y,
+                                                  int lz, int gz,
                                                   bool cur_water, float keep,
                                                   uint32_t* __restrict__ violation) {
     const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
@@ -79,10 +114,10 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
         const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
         const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
         const float qz = (float)gz + (COMP == 2 ? 0.0f : 0.5f);
-        const float vx = sample_comp<0>(v1, g, qx, qy, qz, violation);  // :75
-        const float vy = sample_comp<1>(v1, g, qx, qy, qz, violation);
-        const float vz = sample_comp<2>(v1, g, qx, qy, qz, violation);
-        return sample_comp<COMP>(v1, g, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
+        const float vx = sample_comp<0>(v1, g, axes, qx, qy, qz, violation);  // :75
+        const float vy = sample_comp<1>(v1, g, axes, qx, qy, qz, violation);
+        const float vz = sample_comp<2>(v1, g, axes, qx, qy, qz, violation);
+        return sample_comp<COMP>(v1, g, axes, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
                                  violation);  // :77
     }
     return keep;  // :79
@@ -96,15 +131,16 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
                            uint32_t* __restrict__ violation, const uint8_t* __restrict__ quiet,
                            BrickK bk, int xchunks) {
     FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)  // quiet_bricks.h
+    const Axes axes = make_axes(g);
     FLUID_FOR_CELLS_OF_ROW(xchunks)
     const int gz = g.z0 + lz;
     const int64_t id = cidx(g, x, y, lz);
     const float4 cur = v1[id];                          // :87
     const bool cur_water = (uint32_t)t[id] == p.t_water;  // :93
     float4 o;
-    o.x = advect_component<0>(t, v1, g, p, x, y, lz, gz, cur_water, cur.x, violation);
-    o.y = advect_component<1>(t, v1, g, p, x, y, lz, gz, cur_water, cur.y, violation);
-    o.z = advect_component<2>(t, v1, g, p, x, y, lz, gz, cur_water, cur.z, violation);
+    o.x = advect_component<0>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.x, violation);
+    o.y = advect_component<1>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y, violation);
+    o.z = advect_component<2>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z, violation);
     o.w = 0.0f;
     if (FORCES) {
         const uint32_t t2 = type_at(t, g, x, y - 1, lz);
@@ -133,9 +169,10 @@ __global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict_
     if (i >= capacity) return;
     float4 q = particles[i];
     if (q.w == p.active_w) {  // :48
-        const float vx = sample_comp<0>(v1, g, q.x, q.y, q.z, violation);
-        const float vy = sample_comp<1>(v1, g, q.x, q.y, q.z, violation);
-        const float vz = sample_comp<2>(v1, g, q.x, q.y, q.z, violation);
+        const Axes axes = make_axes(g);
+        const float vx = sample_comp<0>(v1, g, axes, q.x, q.y, q.z, violation);
+        const float vy = sample_comp<1>(v1, g, axes, q.x, q.y, q.z, violation);
+        const float vz = sample_comp<2>(v1, g, axes, q.x, q.y, q.z, violation);
         q.x = q.x + vx * p.dt;  // :50
         q.y = q.y + vy * p.dt;
         q.z = q.z + vz * p.dt;
