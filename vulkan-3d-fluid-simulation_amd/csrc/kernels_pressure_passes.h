@@ -140,9 +140,9 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
 // Residual of the sweep's linear system at a WATER cell, in the sweep's own fp32 arithmetic:
 //     s = b_i - sum over non-solid neighbours of (water ? P[nb] : p_air)      (pressure.comp:54-61)
 //     r = s + aii * P[cell]            (the sweep stores P' = -s / aii, so r = 0 at its fixed point)
-// Per-wavefront reduction with wave64 shuffles, then one atomic per wavefront: max |r| as the bit
-// pattern of a non-negative float (monotonic as an unsigned integer), sum of r^2 and the number of
-// water cells in double / 64-bit.  NaN residuals are ignored by the maximum and poison the sum.
+// Threads accumulate over many cells, wavefronts reduce with wave64 shuffles, workgroups through LDS, then
+// one set of atomics per workgroup (a few thousand in all): max |r| as the bit pattern of a non-negative
+// float (monotonic as an unsigned integer), sum of r^2 and the number of water cells in double / 64-bit.  NaN residuals are ignored by the maximum and poison the sum.
 struct ResidualOut {
     unsigned int max_abs_bits;
     unsigned int pad;
@@ -150,18 +150,21 @@ struct ResidualOut {
     unsigned long long water_cells;
 };
 
-__global__ void k12_residual(const uint8_t* __restrict__ t, const float* __restrict__ div,
-                             const float* __restrict__ pimg, GridK g, ParamsK p,
-                             ResidualOut* __restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int lz = blockIdx.z;
+// launch: 1-D grid of at most a few thousand workgroups of 256 threads; wavefront w of workgroup b walks
+// the rows (y, z) numbered 4 b + w, 4 (b + gridDim.x) + w, ..., its lanes stride over x
+__global__ void __launch_bounds__(256)
+k12_residual(const uint8_t* __restrict__ t, const float* __restrict__ div,
+             const float* __restrict__ pimg, GridK g, ParamsK p, ResidualOut* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float r_abs = 0.0f;
     double r_sq = 0.0;
     unsigned int wet = 0;
-    if (x < g.W && y < g.H) {
-        const int64_t id = cidx(g, x, y, lz);
-        if ((uint32_t)t[id] == p.t_water) {
+    const int64_t rows = (int64_t)g.H * g.Dl;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int y = (int)(row % g.H), lz = (int)(row / g.H);
+        for (int x = lane; x < g.W; x += 64) {
+            const int64_t id = cidx(g, x, y, lz);
+            if ((uint32_t)t[id] != p.t_water) continue;
             int aii = 0;
             float s = ((div[id] * p.rho) * p.dx) / p.dt;
             auto nb = [&](uint32_t ty, float q) {
@@ -182,9 +185,9 @@ __global__ void k12_residual(const uint8_t* __restrict__ t, const float* __restr
             nb(tzm, tzm == p.t_water ? pimg[cidx(g, x, y, lz - 1)] : 0.f);
             const float ap = (float)aii * pimg[id];
             const float r = s + ap;
-            r_abs = fabsf(r);
-            r_sq = (double)r * (double)r;
-            wet = 1;
+            r_abs = fmaxf(r_abs, fabsf(r));
+            r_sq += (double)r * (double)r;
+            wet++;
         }
     }
     // wave64 butterfly: every lane ends with the wavefront's max / sums
@@ -194,10 +197,25 @@ __global__ void k12_residual(const uint8_t* __restrict__ t, const float* __restr
         r_sq += __shfl_xor(r_sq, off, 64);
         wet += __shfl_xor(wet, off, 64);
     }
-    if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && wet != 0) {
-        atomicMax(&out->max_abs_bits, __float_as_uint(r_abs));
-        atomicAdd(&out->sum_sq, r_sq);
-        atomicAdd(&out->water_cells, (unsigned long long)wet);
+    // the four wavefronts of the workgroup through LDS, then one set of atomics per workgroup
+    __shared__ float s_abs[4];
+    __shared__ double s_sq[4];
+    __shared__ unsigned int s_wet[4];
+    if (lane == 0) {
+        s_abs[wave] = r_abs;
+        s_sq[wave] = r_sq;
+        s_wet[wave] = wet;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = fmaxf(fmaxf(s_abs[0], s_abs[1]), fmaxf(s_abs[2], s_abs[3]));
+        const double q = ((s_sq[0] + s_sq[1]) + s_sq[2]) + s_sq[3];
+        const unsigned int n = s_wet[0] + s_wet[1] + s_wet[2] + s_wet[3];
+        if (n != 0) {
+            atomicMax(&out->max_abs_bits, __float_as_uint(m));
+            atomicAdd(&out->sum_sq, q);
+            atomicAdd(&out->water_cells, (unsigned long long)n);
+        }
     }
 }
 

@@ -3,6 +3,8 @@
 #include "kernels_pressure_passes.h"
 #include "pressure_api.h"
 
+#include <algorithm>
+
 namespace fluid {
 
 static dim3 v4_block() { return dim3(64, 4, 1); }
@@ -35,8 +37,10 @@ void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, 
 
 void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
                          const GridK& g, const ParamsK& p, void* out32) {
-    hipLaunchKernelGGL(k12_residual, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.Dl), dim3(64, 4, 1), 0, s, t,
-                       div, pimg, g, p, static_cast<ResidualOut*>(out32));
+    const int64_t rows = (int64_t)g.H * g.Dl;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 4096));
+    hipLaunchKernelGGL(k12_residual, dim3(blocks), dim3(256), 0, s, t, div, pimg, g, p,
+                       static_cast<ResidualOut*>(out32));
 }
 
 }  // namespace fluid
