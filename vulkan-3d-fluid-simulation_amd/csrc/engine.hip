@@ -84,6 +84,9 @@ struct fluid_ctx {
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
     uint64_t active_offset = 0, active_bytes = 0;  // one byte per 256x4x16 brick: holds water?
     uint64_t quiet_offset = 0;    // one byte per brick: steps since water was near (quiet_bricks.h)
+    uint64_t early_offset = 0;    // one byte per brick: 255 = skipped by 02 / 03 / 04+05 of this step
+    uint64_t pbricks_offset = 0;  // one byte per brick: a particle was counted there in this step
+    bool early_in_use = false;    // inside fluid_run_step, between 01 and 06
     bool quiet_valid = false;     // the streaks describe the images (nothing wrote them from outside)
     bool quiet_in_use = false;    // inside fluid_run_step, between 06 and 13: kernels may skip
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
@@ -145,6 +148,9 @@ struct fluid_ctx {
     uint8_t* quiet() const { return arena + quiet_offset; }
     // pointer for the kernels that may skip quiet bricks (null: process everything)
     const uint8_t* quiet_or_null() const { return quiet_in_use ? quiet() : nullptr; }
+    uint8_t* early() const { return arena + early_offset; }
+    uint8_t* pbricks() const { return arena + pbricks_offset; }
+    const uint8_t* early_or_null() const { return early_in_use ? early() : nullptr; }
     uint32_t* flags() const { return reinterpret_cast<uint32_t*>(arena + flags_offset); }
     Leaver* leavers() const { return reinterpret_cast<Leaver*>(arena + leavers_offset); }
     // bookkeeping for the fast path: call whenever an image's device contents change
@@ -237,7 +243,8 @@ ParamsK make_params_k(const fluid_params& p) {
 struct Layout {
     uint64_t img_offset[8], img_bytes[8];
     uint64_t particles_offset, particles_bytes;
-    uint64_t mask_offset, rhs_offset, active_offset, active_bytes, quiet_offset, work_offset[3];
+    uint64_t mask_offset, rhs_offset, active_offset, active_bytes, quiet_offset, early_offset,
+        pbricks_offset, work_offset[3];
     uint64_t flags_offset, leavers_offset;
     uint32_t leavers_capacity;
     uint64_t total;
@@ -277,6 +284,10 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     }
     off = align_up(off + L.active_bytes, kAlign);
     L.quiet_offset = off;
+    off = align_up(off + L.active_bytes, kAlign);
+    L.early_offset = off;
+    off = align_up(off + L.active_bytes, kAlign);
+    L.pbricks_offset = off;
     off = align_up(off + L.active_bytes, kAlign);
     for (int i = 0; i < 3; i++) {
         L.work_offset[i] = off;
@@ -664,6 +675,8 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
 // internal ids of the grouped passes, past the public section ids
 enum : int {
     STEP_0405_EXTRAPOLATE = FLUID_SECTION_COUNT + 1,
+    STEP_01A_CLEAR_WHERE_WATER_WAS,
+    STEP_01_UPDATE_DENSITIES_MARK_BRICKS,
     STEP_0405_APPLY,
     STEP_0708_ADVECT_FORCES,
     STEP_091011_SOLIDS_DIVERGENCE,
@@ -700,25 +713,44 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES:
             return fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
+        case STEP_01A_CLEAR_WHERE_WATER_WAS:  // quiet_bricks.h; bricks() still holds the previous step's map
+            hipLaunchKernelGGL(k_clear_density_where_water_was, cell4_grid(g), block, 0, c->stream, dens,
+                               g, c->bricks(), bk);
+            break;
+        case STEP_01_UPDATE_DENSITIES_MARK_BRICKS: {
+            const int nb = (int)c->active_bytes;
+            HIP_TRY(c, hipMemsetAsync(c->pbricks(), 0, c->active_bytes, c->stream));
+            if (c->particle_capacity != 0) {
+                const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
+                const unsigned blocks =
+                    (unsigned)((c->particle_capacity + per_block - 1) / per_block);
+                hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                                   c->particles(), c->particle_capacity, dens, g, pk, c->pbricks(), bk);
+            }
+            hipLaunchKernelGGL(k_update_early_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
+                               c->bricks(), c->pbricks(), c->early(), bk);
+            break;
+        }
         case FLUID_SEC_01_UPDATE_DENSITIES: {
             if (c->particle_capacity == 0) return FLUID_OK;
             const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
             const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
             hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
-                               c->particles(), c->particle_capacity, dens, g, pk);
+                               c->particles(), c->particle_capacity, dens, g, pk,
+                               (uint8_t*)nullptr, bk);
             break;
         }
         case FLUID_SEC_02_UPDATE_WATER:
             if (g.W % 4 == 0)
                 hipLaunchKernelGGL(k02_update_water_v4, cell4_grid(g), block, 0, c->stream, dens,
-                                   newT, g, pk);
+                                   newT, g, pk, c->early_or_null(), bk);
             else
                 hipLaunchKernelGGL(k02_update_water, grid, block, 0, c->stream, dens, newT, g, pk);
             break;
         case FLUID_SEC_03_UPDATE_AIR:
             if (g.W % 4 == 0)
                 hipLaunchKernelGGL(k03_update_air_v4, cell4_grid(g), block, 0, c->stream, newT, g,
-                                   pk);
+                                   pk, c->early_or_null(), bk);
             else
                 hipLaunchKernelGGL(k03_update_air, grid, block, 0, c->stream, newT, g, pk);
             break;
@@ -733,10 +765,11 @@ int run_section_impl(fluid_ctx* c, int section) {
         // grouped passes of fluid_run_step (kernels_step_fused.h); not part of the public section ids
         case STEP_0405_EXTRAPOLATE:
             hipLaunchKernelGGL(k0405_extrapolate, cell4_grid(g), block, 0, c->stream, T, newT, V1, V2,
-                               g, pk);
+                               g, pk, c->early_or_null(), bk);
             break;
         case STEP_0405_APPLY:
-            hipLaunchKernelGGL(k0405_apply, cell4_grid(g), block, 0, c->stream, T, newT, V2, V1, g, pk);
+            hipLaunchKernelGGL(k0405_apply, cell4_grid(g), block, 0, c->stream, T, newT, V2, V1, g, pk,
+                               c->early_or_null(), bk);
             break;
         case STEP_0708_ADVECT_FORCES:
             hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
@@ -979,6 +1012,8 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->active_offset = L.active_offset;
     c->active_bytes = L.active_bytes;
     c->quiet_offset = L.quiet_offset;
+    c->early_offset = L.early_offset;
+    c->pbricks_offset = L.pbricks_offset;
     for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
     c->flags_offset = L.flags_offset;
     c->leavers_offset = L.leavers_offset;
@@ -1379,8 +1414,23 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
                        c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT &&
                        c->opt[FLUID_OPT_QUIET_BRICKS] == 0;
     c->quiet_in_use = false;
+    // the one-step test for the sections before 06 needs the previous step's water map in bricks():
+    // nothing may have written the images since that step (quiet_valid still set)
+    const bool early = quiet && c->quiet_valid && c->mask_valid &&
+                       first == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES;
+    c->early_in_use = false;
     for (int s = first; s < end;) {
         int rc, used = 1;
+        if (early && s == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES) {
+            rc = timed_section(c, s, STEP_01A_CLEAR_WHERE_WATER_WAS);
+            if (rc == FLUID_OK)
+                rc = timed_section(c, FLUID_SEC_01_UPDATE_DENSITIES, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
+            if (rc) return rc;
+            c->early_in_use = true;
+            s += 2;
+            continue;
+        }
+        if (s == FLUID_SEC_06_UPDATE_CELL_TYPES) c->early_in_use = false;
         if (quiet && s == FLUID_SEC_07_ADVECT) {
             // CELL_TYPES of this step is final (06): activity bricks now, then the streaks
             rc = ensure_prepared(c, true);
@@ -1416,13 +1466,13 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
             rc = timed_section(c, s);
         }
         if (rc) {
-            c->quiet_in_use = false;
+            c->quiet_in_use = c->early_in_use = false;
             return rc;
         }
         if (s == FLUID_SEC_13_FIX_DIVERGENCE) c->quiet_in_use = false;
         s += used;
     }
-    c->quiet_in_use = false;
+    c->quiet_in_use = c->early_in_use = false;
     return FLUID_OK;
 }
 

@@ -84,7 +84,8 @@ __global__ void k03_update_air(uint8_t* __restrict__ t, GridK g, ParamsK p) {
     const int gz = g.z0 + lz;
 
 __global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* __restrict__ newT,
-                                    GridK g, ParamsK p) {
+                                    GridK g, ParamsK p, const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // quiet_bricks.h (02 and 03 skip the same bricks)
     FLUID_CELL4_THREAD();
     (void)gz;
     const uint4 d = *reinterpret_cast<const uint4*>(dens + id);
@@ -93,7 +94,9 @@ __global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* 
     *reinterpret_cast<uint32_t*>(newT + id) = a | (b << 8) | (c << 16) | (e << 24);
 }
 
-__global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p) {
+__global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p,
+                                  const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
     FLUID_CELL4_THREAD();
     auto word = [&](int yy, int llz) -> uint32_t {  // interior rows only: always inside the image
         return *reinterpret_cast<const uint32_t*>(t + cidx(g, x, yy, llz));

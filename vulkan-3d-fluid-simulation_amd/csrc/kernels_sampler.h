@@ -272,7 +272,16 @@ constexpr uint32_t K01_EMPTY = 0xFFFFFFFFu;
 
 __global__ void __launch_bounds__(K01_THREADS)
 k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
-                     uint32_t* __restrict__ dens, GridK g, ParamsK p) {
+                     uint32_t* __restrict__ dens, GridK g, ParamsK p,
+                     uint8_t* __restrict__ particle_bricks, BrickK bk) {
+    // particle_bricks (optional): one byte per activity brick, set where a particle is counted
+    // (quiet_bricks.h: the sections before 06 skip bricks far from old and new water)
+    auto mark = [&](uint32_t key) {
+        if (particle_bricks) {
+            const int x = (int)(key % (uint32_t)g.W), yz = (int)(key / (uint32_t)g.W);
+            particle_bricks[brick_index(bk, x / BRICK_X, (yz % g.H) / BRICK_Y, (yz / g.H) / BRICK_Z)] = 1;
+        }
+    };
     __shared__ uint32_t keys[K01_TABLE];
     __shared__ uint32_t counts[K01_TABLE];
     for (int i = threadIdx.x; i < K01_TABLE; i += K01_THREADS) {
@@ -304,12 +313,18 @@ k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
             }
             h = (h + 1) & (K01_TABLE - 1);
         }
-        if (!placed) atomicAdd(&dens[key], 1u);  // table crowded: fall through to a global atomic
+        if (!placed) {  // table crowded: fall through to a global atomic
+            atomicAdd(&dens[key], 1u);
+            mark(key);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K01_TABLE; i += K01_THREADS) {
         const uint32_t key = keys[i];
-        if (key != K01_EMPTY) atomicAdd(&dens[key], counts[i]);
+        if (key != K01_EMPTY) {
+            atomicAdd(&dens[key], counts[i]);
+            mark(key);
+        }
     }
 }
 

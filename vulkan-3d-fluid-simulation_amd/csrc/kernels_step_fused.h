@@ -53,6 +53,42 @@ __global__ void k_update_quiet(const uint8_t* __restrict__ active, uint8_t* __re
 }
 
 
+// early[b] = 255 where brick b and its 26 neighbours neither held water after the previous step (`old_water`)
+// nor receive a particle in this one (`particle_bricks`), else 0 (quiet_bricks.h)
+__global__ void k_update_early_quiet(const uint8_t* __restrict__ old_water,
+                                     const uint8_t* __restrict__ particle_bricks,
+                                     uint8_t* __restrict__ early, BrickK bk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = bk.nbx * bk.nby * bk.nbz;
+    if (i >= n) return;
+    const int bx = i % bk.nbx, by = (i / bk.nbx) % bk.nby, bz = i / (bk.nbx * bk.nby);
+    uint32_t any = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                if ((unsigned)x < (unsigned)bk.nbx && (unsigned)y < (unsigned)bk.nby &&
+                    (unsigned)z < (unsigned)bk.nbz) {
+                    const int j = brick_index(bk, x, y, z);
+                    any |= (uint32_t)old_water[j] | (uint32_t)particle_bricks[j];
+                }
+            }
+    early[i] = any ? 0 : 255;
+}
+
+// 01a inside fluid_run_step: the density image is non-zero only where the previous step had water
+// (02: WATER <=> density > 0), so only those bricks are cleared.  cell4_grid() / cell_block().
+__global__ void k_clear_density_where_water_was(uint32_t* __restrict__ dens, GridK g,
+                                                const uint8_t* __restrict__ old_water, BrickK bk) {
+    if (old_water[brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X, (int)(blockIdx.y * 4u) / BRICK_Y,
+                              (int)blockIdx.z / BRICK_Z)] == 0)
+        return;
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.W || y >= g.H) return;
+    *reinterpret_cast<uint4*>(dens + cidx(g, x, y, (int)blockIdx.z)) = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ---- 04 + 05 ------------------------------------------------------------------------------------------
 // Per-component state of 05 (extrapolate_velocities.comp:48-56) for the four cells x..x+3 of a row:
 // bits [2c, 2c+1] of byte i = component c of cell i: 1 = VELOCITY_RESET, 2 = VELOCITY_EXTRAPOLATE.
@@ -100,7 +136,8 @@ constexpr uint32_t STATE_ANY_EXTRAPOLATE = 0x2Au;  // bits of the three "2" stat
 // (extrapolated_velocities.comp:37-63) for cells with a component in state VELOCITY_EXTRAPOLATE.
 __global__ void k0405_extrapolate(const uint8_t* __restrict__ oldT, const uint8_t* __restrict__ newT,
                                   const float4* __restrict__ v1, float4* __restrict__ v2, GridK g,
-                                  ParamsK p) {
+                                  ParamsK p, const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
     FLUID_CELL4_ROW_THREAD();
     const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);
     if ((st & (STATE_ANY_EXTRAPOLATE * 0x01010101u)) == 0u) return;
@@ -139,7 +176,8 @@ __global__ void k0405_extrapolate(const uint8_t* __restrict__ oldT, const uint8_
 // EXTRAPOLATE component keep their bits (w is 0 already, see the header comment).
 __global__ void k0405_apply(const uint8_t* __restrict__ oldT, const uint8_t* __restrict__ newT,
                             const float4* __restrict__ v2, float4* __restrict__ v1, GridK g,
-                            ParamsK p) {
+                            ParamsK p, const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
     FLUID_CELL4_ROW_THREAD();
     (void)gz;
     const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);

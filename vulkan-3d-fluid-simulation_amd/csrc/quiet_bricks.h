@@ -19,6 +19,13 @@ namespace fluid {
 // such a brick is 0 where the list has 1 between 10 and 13 — nobody reads it there).  Any write from
 // outside fluid_run_step (uploads, clears, single sections, parameters) resets the streaks.
 constexpr uint32_t QUIET_MIN_STREAK = 3;
+// Sections 01a-05 run before the step's own map exists; they use a second, one-step test instead
+// (k_update_early_quiet, after 01): a brick is skipped when neither it nor any of its 26 neighbours held
+// water after the previous step (the activity bricks still in memory) or receives a particle in this one
+// (bytes set by 01_update_densities).  There the density is already 0 (01a), 02 followed by 03 rewrites
+// the types that are there (border SOLID -> INACTIVE -> SOLID, the rest INACTIVE; no AIR without water
+// within a cell), and no cell's activity changes (04 + 05).  Encoded as streak 255 / 0 in an array of its
+// own, so the same test macro applies.
 
 
 // for kernels launched with cell_grid() / cell_block() (64 x 4 x 1 cells per workgroup): one brick per
