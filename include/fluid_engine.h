@@ -394,6 +394,8 @@ typedef enum fluid_option {
                                    /* skip bricks of 256x4x16 cells that have had no water in or   */
                                    /* next to them for three steps — a step changes nothing there  */
                                    /* (default); 1 = process every cell                             */
+    FLUID_OPT_ADVECT_KERNEL = 4,   /* 07_advect: 0 = velocity sampler tiled into LDS (default), 1 = taps    */
+                                   /* straight from global memory                                    */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

@@ -785,3 +785,23 @@ def test_pressure_fused_x_window_launches(size, xr, iters):
         eng.solve_pressure(iters)
         st.solve_pressure(iters)
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx=f"x window {xr}: ")
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("size,dt,scale", [((64, 12, 9), 0.01, 3.0), ((24, 20, 16), 0.3, 3.0),
+                                           ((260, 6, 5), 2.0, 3.0), ((17, 13, 9), 1.0, 8.0)])
+def test_advect_tiled_sampler_and_fallback(kernel, size, dt, scale):
+    """07_advect with the LDS-tiled sampler (default) and with direct loads, for back-traces that stay in
+    the tile (small dt * v), that leave it (dt * v of several cells: global fallback) and that leave the
+    grid (clamp to edge)."""
+    st = random_state(size, seed=17, velocity_scale=scale)
+    st.params.time_delta = dt
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_ADVECT_KERNEL, kernel)
+        eng.run_section("07_advect")
+        st.run_section("07_advect")
+        assert_state_equal(eng, st, ctx=f"07 kernel {kernel} dt {dt}: ")
+        eng.run_section_group("07_advect", 2)
+        st.run_section("07_advect")
+        st.run_section("08_forces")
+        assert_state_equal(eng, st, ctx=f"07+08 kernel {kernel} dt {dt}: ")

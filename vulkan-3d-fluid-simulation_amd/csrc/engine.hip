@@ -772,8 +772,12 @@ int run_section_impl(fluid_ctx* c, int section) {
                                c->early_or_null(), bk);
             break;
         case STEP_0708_ADVECT_FORCES:
-            hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags(), c->quiet_or_null(), bk, qchunks);
+            if (c->opt[FLUID_OPT_ADVECT_KERNEL] == 1)
+                hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
+                                   c->flags(), c->quiet_or_null(), bk, qchunks);
+            else
+                hipLaunchKernelGGL(k07_advect_tiled<true>, qgrid, block, 0, c->stream, T, V1, V2, g,
+                                   pk, c->flags(), c->quiet_or_null(), bk, qchunks);
             break;
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
@@ -790,8 +794,12 @@ int run_section_impl(fluid_ctx* c, int section) {
                                       hipMemcpyDeviceToDevice, c->stream));
             return FLUID_OK;
         case FLUID_SEC_07_ADVECT:
-            hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
-                               c->flags(), (const uint8_t*)nullptr, bk, 1);
+            if (c->opt[FLUID_OPT_ADVECT_KERNEL] == 1)
+                hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
+                                   c->flags(), (const uint8_t*)nullptr, bk, 1);
+            else
+                hipLaunchKernelGGL(k07_advect_tiled<false>, grid, block, 0, c->stream, T, V1, V2, g,
+                                   pk, c->flags(), (const uint8_t*)nullptr, bk, 1);
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);

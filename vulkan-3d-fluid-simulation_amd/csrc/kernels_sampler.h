@@ -63,13 +63,31 @@ __device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0,
 }
 __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f - a) * A + a * B; }
 
+// Velocity tile in LDS (k07_advect_tiled): the cells of a workgroup plus TILE_HALO cells around them,
+// one array per component so that neighbouring lanes read neighbouring banks.  Tile cell (tx, ty, tz)
+// holds the texel at grid index (x_org + tx, y_org + ty, local plane z_org + tz); cells outside the
+// image are never addressed (taps are clamped into the image before the lookup).
+#define FLUID_LDS_F __attribute__((address_space(3)))
+constexpr int TILE_HALO = 2;
+constexpr int TILE_W = 64 + 2 * TILE_HALO, TILE_H = 4 + 2 * TILE_HALO, TILE_D = 1 + 2 * TILE_HALO;
+constexpr int TILE_CELLS = TILE_W * TILE_H * TILE_D;
+struct NoTile {
+    static constexpr bool enabled = false;
+};
+struct VelTile {
+    static constexpr bool enabled = true;
+    const FLUID_LDS_F float* comp[3];
+    int x_org, y_org, z_org;
+};
+
 // Component COMP of the trilinear sample at world position (px,py,pz).  `v` addresses owned plane 0
 // of an RGBA32F image; z taps are global indices converted to local planes (whole-grid contexts
 // have z0 = 0).  The eight taps are scalar loads of one channel of the texel.
-template <int COMP>
+template <int COMP, typename Tile = NoTile>
 __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const GridK& g,
                                              const Axes& axes, float px, float py, float pz,
-                                             uint32_t* __restrict__ violation) {
+                                             uint32_t* __restrict__ violation,
+                                             const Tile& tile = Tile()) {
     const float mx = COMP == 0 ? 0.5f : 0.0f, my = COMP == 1 ? 0.5f : 0.0f,
                 mz = COMP == 2 ? 0.5f : 0.0f;
     int x0, x1, y0, y1, z0, z1;
@@ -88,24 +106,45 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
             z1 = min(max(z1, lo), hi);
         }
     }
-    const float* __restrict__ f = reinterpret_cast<const float*>(v) + COMP;
-    const float c000 = f[4 * cidx(g, x0, y0, z0)], c100 = f[4 * cidx(g, x1, y0, z0)];
-    const float c010 = f[4 * cidx(g, x0, y1, z0)], c110 = f[4 * cidx(g, x1, y1, z0)];
-    const float c001 = f[4 * cidx(g, x0, y0, z1)], c101 = f[4 * cidx(g, x1, y0, z1)];
-    const float c011 = f[4 * cidx(g, x0, y1, z1)], c111 = f[4 * cidx(g, x1, y1, z1)];
+    float c000 = 0.f, c100 = 0.f, c010 = 0.f, c110 = 0.f, c001 = 0.f, c101 = 0.f, c011 = 0.f, c111 = 0.f;
+    bool from_tile = false;
+    if constexpr (Tile::enabled) {
+        const int tx0 = x0 - tile.x_org, tx1 = x1 - tile.x_org, ty0 = y0 - tile.y_org,
+                  ty1 = y1 - tile.y_org, tz0 = z0 - tile.z_org, tz1 = z1 - tile.z_org;
+        from_tile = (unsigned)tx0 < (unsigned)TILE_W && (unsigned)tx1 < (unsigned)TILE_W &&
+                    (unsigned)ty0 < (unsigned)TILE_H && (unsigned)ty1 < (unsigned)TILE_H &&
+                    (unsigned)tz0 < (unsigned)TILE_D && (unsigned)tz1 < (unsigned)TILE_D;
+        if (from_tile) {
+            const FLUID_LDS_F float* t = tile.comp[COMP];
+            const int r00 = TILE_W * (ty0 + TILE_H * tz0), r10 = TILE_W * (ty1 + TILE_H * tz0);
+            const int r01 = TILE_W * (ty0 + TILE_H * tz1), r11 = TILE_W * (ty1 + TILE_H * tz1);
+            c000 = t[r00 + tx0]; c100 = t[r00 + tx1];
+            c010 = t[r10 + tx0]; c110 = t[r10 + tx1];
+            c001 = t[r01 + tx0]; c101 = t[r01 + tx1];
+            c011 = t[r11 + tx0]; c111 = t[r11 + tx1];
+        }
+    }
+    if (!from_tile) {
+        const float* __restrict__ f = reinterpret_cast<const float*>(v) + COMP;
+        c000 = f[4 * cidx(g, x0, y0, z0)]; c100 = f[4 * cidx(g, x1, y0, z0)];
+        c010 = f[4 * cidx(g, x0, y1, z0)]; c110 = f[4 * cidx(g, x1, y1, z0)];
+        c001 = f[4 * cidx(g, x0, y0, z1)]; c101 = f[4 * cidx(g, x1, y0, z1)];
+        c011 = f[4 * cidx(g, x0, y1, z1)]; c111 = f[4 * cidx(g, x1, y1, z1)];
+    }
     const float c00 = lerp1(c000, c100, ax), c10 = lerp1(c010, c110, ax);
     const float c01 = lerp1(c001, c101, ax), c11 = lerp1(c011, c111, ax);
     const float c0 = lerp1(c00, c10, ay), c1 = lerp1(c01, c11, ay);
     return lerp1(c0, c1, az);
 }
 
-template <int COMP>
+template <int COMP, typename Tile = NoTile>
 __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
                                                   const float4* __restrict__ v1, const GridK& g,
                                                   const Axes& axes, const ParamsK& p, int x, int y,
                                                   int lz, int gz,
                                                   bool cur_water, float keep,
-                                                  uint32_t* __restrict__ violation) {
+                                                  uint32_t* __restrict__ violation,
+                                                  const Tile& tile = Tile()) {
     const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
     // advect.comp:65-68: move[c] = -1; cellAt(pos - move) is the cell at pos + e_c
     const uint32_t nt =
@@ -114,13 +153,33 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
         const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
         const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
         const float qz = (float)gz + (COMP == 2 ? 0.0f : 0.5f);
-        const float vx = sample_comp<0>(v1, g, axes, qx, qy, qz, violation);  // :75
-        const float vy = sample_comp<1>(v1, g, axes, qx, qy, qz, violation);
-        const float vz = sample_comp<2>(v1, g, axes, qx, qy, qz, violation);
-        return sample_comp<COMP>(v1, g, axes, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
-                                 violation);  // :77
+        const float vx = sample_comp<0, Tile>(v1, g, axes, qx, qy, qz, violation, tile);  // :75
+        const float vy = sample_comp<1, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+        const float vz = sample_comp<2, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+        return sample_comp<COMP, Tile>(v1, g, axes, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
+                                       violation, tile);  // :77
     }
     return keep;  // :79
+}
+
+// 08_forces on the value 07 produced (forces.comp:33-54), shared by both advect kernels
+__device__ __forceinline__ float4 forces_on(float4 o, const uint8_t* __restrict__ t, const GridK& g,
+                                            const ParamsK& p, int x, int y, int lz, int gz,
+                                            bool cur_water) {
+    const uint32_t t2 = type_at(t, g, x, y - 1, lz);
+    const bool wet = cur_water || (t2 == p.t_water);
+    float fy = 0.0f;
+    if (y != 0 && wet) fy += p.gravity;  // :39-45
+    if ((uint32_t)x == p.fountain[0] && (uint32_t)y == p.fountain[1] &&
+        (uint32_t)gz == p.fountain[2] && wet)
+        fy += p.fountain_force;  // :47-49
+    if (fy != 0.0f) {            // :52-53
+        o.x = o.x + p.dt * 0.0f;
+        o.y = o.y + p.dt * fy;
+        o.z = o.z + p.dt * 0.0f;
+        o.w = o.w + 0.0f;
+    }
+    return o;
 }
 
 // 07_advect/advect.comp:84-97.  FORCES: 08_forces/forces.comp:33-54 applied to the value before it is
@@ -142,23 +201,84 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
     o.y = advect_component<1>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y, violation);
     o.z = advect_component<2>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z, violation);
     o.w = 0.0f;
-    if (FORCES) {
-        const uint32_t t2 = type_at(t, g, x, y - 1, lz);
-        const bool wet = cur_water || (t2 == p.t_water);
-        float fy = 0.0f;
-        if (y != 0 && wet) fy += p.gravity;  // forces.comp:39-45
-        if ((uint32_t)x == p.fountain[0] && (uint32_t)y == p.fountain[1] &&
-            (uint32_t)gz == p.fountain[2] && wet)
-            fy += p.fountain_force;  // :47-49
-        if (fy != 0.0f) {            // :52-53
-            o.x = o.x + p.dt * 0.0f;
-            o.y = o.y + p.dt * fy;
-            o.z = o.z + p.dt * 0.0f;
-            o.w = o.w + 0.0f;
-        }
-    }
+    if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water);
     v2[id] = o;  // :96
     FLUID_END_FOR_CELLS
+}
+
+// 07_advect (+ 08_forces) with the velocity sampler tiled into LDS.  A workgroup of 64 x 4 cells of one
+// plane first votes whether any of its cells is advected at all (cell or +x/+y/+z neighbour WATER,
+// advect.comp:65-68); if so it stages the velocities of its cells and TILE_HALO cells around them in LDS
+// (coalesced float4 loads along x, stored per component), and the twelve trilinear samples per cell
+// (three at the face position for the back-trace, one at the back-traced position, per component) read
+// their 8 taps from the tile: the face-position samples always lie inside it, a back-trace that leaves
+// it (more than TILE_HALO cells away) falls back to global loads.  Same arithmetic as k07_advect.
+template <bool FORCES>
+__global__ void __launch_bounds__(256)
+k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
+                 float4* __restrict__ v2, GridK g, ParamsK p, uint32_t* __restrict__ violation,
+                 const uint8_t* __restrict__ quiet, BrickK bk, int xchunks) {
+    FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)  // quiet_bricks.h
+    __shared__ float tile_mem[3][TILE_CELLS];
+    const Axes axes = make_axes(g);
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int lz = blockIdx.z;
+    const int gz = g.z0 + lz;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // planes of the image that exist for this context (ghost planes of a slab; the grid itself otherwise)
+    const int zlo = max(-IMG_GHOST, -g.z0), zhi = min(g.Dl + IMG_GHOST - 1, g.Dg - 1 - g.z0);
+    for (int xc = 0; xc < xchunks; xc++) {
+        const int xb = ((int)blockIdx.x * xchunks + xc) * 64;  // first cell of this chunk
+        if (xb >= g.W) break;                                  // uniform
+        const int x = xb + (int)threadIdx.x;
+        const bool valid = x < g.W && y < g.H;
+        int64_t id = 0;
+        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool cur_water = false, adv = false;
+        if (valid) {
+            id = cidx(g, x, y, lz);
+            cur = v1[id];                                   // :87
+            cur_water = (uint32_t)t[id] == p.t_water;       // :93
+            adv = cur_water || type_at(t, g, x + 1, y, lz) == p.t_water ||
+                  type_at(t, g, x, y + 1, lz) == p.t_water ||
+                  (uint32_t)t[cidx(g, x, y, lz + 1)] == p.t_water;
+        }
+        const bool any_adv = __syncthreads_or(adv ? 1 : 0) != 0;  // also fences the previous chunk's reads
+        VelTile tile;
+        tile.comp[0] = (const FLUID_LDS_F float*)tile_mem[0];
+        tile.comp[1] = (const FLUID_LDS_F float*)tile_mem[1];
+        tile.comp[2] = (const FLUID_LDS_F float*)tile_mem[2];
+        tile.x_org = xb - TILE_HALO;
+        tile.y_org = (int)blockIdx.y * 4 - TILE_HALO;
+        tile.z_org = lz - TILE_HALO;
+        if (any_adv) {
+            for (int i = tid; i < TILE_CELLS; i += 256) {
+                const int tx = i % TILE_W, ty = (i / TILE_W) % TILE_H, tz = i / (TILE_W * TILE_H);
+                const int cx = tile.x_org + tx, cy = tile.y_org + ty, cz = tile.z_org + tz;
+                if ((unsigned)cx < (unsigned)g.W && (unsigned)cy < (unsigned)g.H && cz >= zlo && cz <= zhi) {
+                    const float4 q = v1[cidx(g, cx, cy, cz)];
+                    tile_mem[0][i] = q.x;
+                    tile_mem[1][i] = q.y;
+                    tile_mem[2][i] = q.z;
+                }
+            }
+            __syncthreads();
+        }
+        if (valid) {
+            float4 o = cur;
+            if (adv) {
+                o.x = advect_component<0, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.x,
+                                                   violation, tile);
+                o.y = advect_component<1, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y,
+                                                   violation, tile);
+                o.z = advect_component<2, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z,
+                                                   violation, tile);
+            }
+            o.w = 0.0f;
+            if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water);
+            v2[id] = o;  // :96
+        }
+    }
 }
 
 // 14_particles/particles.comp:45-51

@@ -49,6 +49,7 @@ OPT_PRESSURE_KERNEL = 0
 OPT_JACOBI_FUSE = 1
 OPT_STEP_FUSION = 2
 OPT_QUIET_BRICKS = 3
+OPT_ADVECT_KERNEL = 4
 STAT_BRICKS, STAT_QUIET_BRICKS = 0, 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
