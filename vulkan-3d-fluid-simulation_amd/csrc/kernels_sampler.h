@@ -415,26 +415,40 @@ k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
         const uint64_t i = base + (uint64_t)k * K01_THREADS + threadIdx.x;  // coalesced 16-B loads
         if (i >= capacity) break;
         const float4 q = particles[i];
-        if (!(q.w == p.active_w)) continue;  // :33
+        // cell this particle counts towards, or K01_EMPTY (inactive, outside the grid, another slab's)
+        uint32_t key = K01_EMPTY;
         int cx, cy, cz;
-        if (!(trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) && trunc_index(q.z, g.Dg, cz)))
-            continue;
-        cz -= g.z0;  // slab contexts count only their own planes
-        if ((unsigned)cz >= (unsigned)g.Dl) continue;
-        const uint32_t key = (uint32_t)cidx(g, cx, cy, cz);
+        if (q.w == p.active_w &&  // :33
+            trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) && trunc_index(q.z, g.Dg, cz)) {
+            cz -= g.z0;  // slab contexts count only their own planes
+            if ((unsigned)cz < (unsigned)g.Dl) key = (uint32_t)cidx(g, cx, cy, cz);
+        }
+        // Neighbouring lanes hold neighbouring particles, which mostly share a cell: the first lane of
+        // every run of equal keys adds the whole run (wave64 shuffle + ballot), so a cell with two
+        // particles in a row costs one pair of LDS atomics instead of two.
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const int lane = (int)(threadIdx.x & 63u);
+        const bool leader = lane == 0 || key != prev;
+        const unsigned long long leaders = __builtin_amdgcn_ballot_w64(leader);
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(true);  // lanes still in the loop
+        if (!leader || key == K01_EMPTY) continue;
+        const unsigned long long after = lane == 63 ? 0ull : (leaders >> (lane + 1));
+        const int live_end = 64 - __builtin_clzll(live);  // lanes [0, live_end) took part
+        const int run_end = after ? lane + 1 + __builtin_ctzll(after) : live_end;
+        const uint32_t run = (uint32_t)(run_end - lane);
         uint32_t h = (key * 2654435761u) >> 20;  // top 12 bits -> [0, 4096)
         bool placed = false;
         for (int probe = 0; probe < 16; probe++) {
             const uint32_t old = atomicCAS(&keys[h], K01_EMPTY, key);
             if (old == K01_EMPTY || old == key) {
-                atomicAdd(&counts[h], 1u);
+                atomicAdd(&counts[h], run);
                 placed = true;
                 break;
             }
             h = (h + 1) & (K01_TABLE - 1);
         }
         if (!placed) {  // table crowded: fall through to a global atomic
-            atomicAdd(&dens[key], 1u);
+            atomicAdd(&dens[key], run);
             mark(key);
         }
     }
