@@ -76,14 +76,14 @@ def grid_dims(grid):
 
 def cpu_baseline_jacobi(size, iters_hint):
     """Oracle (single thread) on a bounded sample of the Jacobi workload: a slab of the same XY
-    extent, `planes` deep, full-fluid inputs; sized for ~10-20 s of CPU work."""
+    extent, `planes` deep, full-fluid inputs; sized for 10-20 s of CPU work."""
     import fluid_amd
     from fluid_amd import scenes
     from oracle_binding import OracleState
 
     w, h, d = size
     planes = max(4, min(d, (1 << 24) // (w * h)))   # ~16.7 M cells
-    sweeps = 24
+    sweeps = 64   # ~12 s on one core of the GPU box's host
     p = fluid_amd.default_params(w, h, planes, 0)
     st = OracleState(p, 0, sweeps)
     st.cell_types[...] = scenes.full_fluid_types(st.shape)
