@@ -310,8 +310,12 @@ def main():
                            "parallelism": f"zslab{world}"},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "k12_canon (per GPU, slab)",
-                             "kernel_ms": kernel_ms},
+                             "kernel": "k12_canon2 (per GPU, on its slab; two sweeps per launch)"
+                                       if w % 4 == 0 and w <= 1024 else "k12_zmarch / k12_plain",
+                             "kernel_ms_per_sweep": kernel_ms,
+                             "note": "achieved = 13 B x local cells / kernel time per sweep (HIP events "
+                                     "on the engine's stream, MAX over ranks); ghost-plane recompute "
+                                     "of the deep halos is inside that time"},
                 "halo_exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
                 "halo_depth": halo,
                 "halo_overlap": result.get("halo_overlap"),
