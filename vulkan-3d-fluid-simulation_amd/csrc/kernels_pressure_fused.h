@@ -136,8 +136,12 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
 //                       Valid when every water cell of the grid lies inside the window: the columns
 //                       just outside it then hold non-water constants, the same in every iterate, which
 //                       the edge lanes load into the pad cells of the LDS rows.
+//   xcd_rows, xcd_nz    (experiment) > 0: the launch is a 1-D grid; workgroup L runs on XCD L % 8 (the
+//                       dispatcher deals workgroups to the 8 XCDs in turn) and takes tile L / 8 of that
+//                       XCD's own list — a band of row tiles x all z chunks — so that workgroups which
+//                       share halo rows share an L2.  xcd_rows = row tiles in the launch, xcd_nz = chunks.
 struct FusedRange {
-    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0;
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0, xcd_rows, xcd_nz;
 };
 
 // Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
@@ -337,13 +341,25 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const int tx = wave % NT;
     c.rr = wave / NT;
     c.x0 = tx * 256 + c.lane * 4;
-    const int y0 = ((int)blockIdx.y + rg.ytile0) * TY;  // first output row
+    int tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
+    if (rg.xcd_rows > 0) {
+        const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
+        // band of XCD `xcd`: rows [r0, r0 + nr) of the launch's row tiles (the first xcd_rows % 8 bands get
+        // one more)
+        const int base = rg.xcd_rows >> 3, extra = rg.xcd_rows & 7;
+        const int nr = base + (xcd < extra ? 1 : 0);
+        const int r0 = xcd * base + min(xcd, extra);
+        if (slot >= nr * rg.xcd_nz) return;  // padding of the shorter lists (uniform)
+        tile_z = slot / nr;
+        tile_y = r0 + slot - tile_z * nr;
+    }
+    const int y0 = (tile_y + rg.ytile0) * TY;  // first output row
     const int y = y0 - 1 + c.rr;           // this wavefront's row
-    if ((int)blockIdx.z < rg.nz_lo) {
-        c.zb = rg.zout_lo + blockIdx.z * zchunk;
+    if (tile_z < rg.nz_lo) {
+        c.zb = rg.zout_lo + tile_z * zchunk;
         c.ze = min(c.zb + zchunk, rg.hole_lo);
     } else {
-        c.zb = rg.hole_hi + ((int)blockIdx.z - rg.nz_lo) * zchunk;
+        c.zb = rg.hole_hi + (tile_z - rg.nz_lo) * zchunk;
         c.ze = min(c.zb + zchunk, rg.zout_hi);
     }
 

@@ -22,6 +22,7 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.hole_lo = rg.hole_hi = rg.zout_hi;
     rg.nz_lo = 0;
     rg.xwin0 = 0;
+    rg.xcd_rows = rg.xcd_nz = 0;
     const int nt = (g.W + 255) / 256;
     // Sparse scene, whole-grid context: if the bricks that hold water span one or two 256-cell columns of
     // a wider grid, launch over that x window only (fewer lanes, more rows per workgroup).

@@ -119,7 +119,16 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
         zchunk = std::min(zchunk, 24);
     if (const char* e = getenv("FLUID_FUSED_ZCHUNK")) zchunk = std::max(1, atoi(e));  // tuning aid
     r.nz_lo = (seg1 + zchunk - 1) / zchunk;
-    const dim3 grid(1, by, r.nz_lo + (seg2 + zchunk - 1) / zchunk);
+    const int nz = r.nz_lo + (seg2 + zchunk - 1) / zchunk;
+    dim3 grid(1, by, nz);
+    r.xcd_rows = r.xcd_nz = 0;
+    if (const char* e = getenv("FLUID_FUSED_XCD")) {  // experiment: XCD-local bands of row tiles
+        if (atoi(e) != 0 && by >= 8) {
+            r.xcd_rows = by;
+            r.xcd_nz = nz;
+            grid = dim3(8 * ((by + 7) / 8) * nz, 1, 1);
+        }
+    }
     BrickK bk;
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
