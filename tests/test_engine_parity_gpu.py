@@ -506,7 +506,7 @@ def test_pressure_fast_path_invalidation():
 
 
 @pytest.mark.parametrize("size", [(64, 40, 24), (256, 13, 9), (512, 19, 35), (260, 6, 5), (768, 7, 6),
-                                  (1024, 5, 4), (8, 8, 8)])
+                                  (1024, 5, 4), (8, 8, 8), (1280, 6, 5)])
 @pytest.mark.parametrize("iters", [2, 3, 4, 5, 6, 7, 8, 12])
 def test_pressure_fused_pairs_match_oracle(size, iters):
     """Two sweeps per pass (kernels_pressure_fused.h): every pairing case of the loop schedule —
