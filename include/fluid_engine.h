@@ -69,9 +69,9 @@ typedef enum fluid_image_id {
     FLUID_IMG_PRESSURES_2 = 5,
     FLUID_IMG_DIVERGENCES = 6,
     FLUID_IMG_PARTICLE_DENSITIES_IMG = 7,
-    /* 8..11 = DETAILED_DENSITIES_IMG, DETAILED_DENSITIES_INERTIA_IMG, PARTICLE_DENSITIES_FLOAT_1/2:
-       surface-render inputs on the 5x grid, not on this path.  Using them
-       returns FLUID_ERR_UNSUPPORTED. */
+    /* 8..11: the surface-prep images on the detailed grid (fluid_size * detailed_resolution per axis,
+       R32UI / R32UI / R32F / R32F).  Contexts created with
+       fluid_create_info.surface_prep only, FLUID_ERR_UNSUPPORTED otherwise. */
     FLUID_IMG_DETAILED_DENSITIES_IMG = 8,
     FLUID_IMG_DETAILED_DENSITIES_INERTIA_IMG = 9,
     FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1 = 10,
@@ -114,7 +114,15 @@ typedef enum fluid_section_id {
     FLUID_SEC_12_SOLVE_PRESSURE = 17,                  /* :300-313 pressure.comp (loop section)    */
     FLUID_SEC_13_FIX_DIVERGENCE = 18,                  /* :314-326 fix_divergence.comp             */
     FLUID_SEC_14_PARTICLES = 19,                       /* :327-338 particles.comp                  */
-    FLUID_SECTION_COUNT = 20
+    /* surface-prep passes on the detailed grid (fluid_flow_sections.h:339-388); contexts created with
+     * fluid_create_info.surface_prep only */
+    FLUID_SEC_14A_CLEAR_DETAILED_DENSITIES = 20,          /* :339                                     */
+    FLUID_SEC_15_UPDATE_DETAILED_DENSITIES = 21,          /* :340-351 update_detailed_densities.comp  */
+    FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA = 22, /* :352-363 densities_inertia.comp          */
+    FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES = 23,            /* :364-375 float_densities.comp            */
+    FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES = 24,            /* :376-388 diffuse_densities.comp (loop)   */
+    FLUID_SEC_INIT_CLEAR_DETAILED_DENSITIES_INERTIA = 25, /* :142 (SimulationInitializationSections)  */
+    FLUID_SECTION_COUNT = 26
 } fluid_section_id;
 
 /* ---- parameters: byte-for-byte the reference's 264-byte std140 uniform block ----------------
@@ -200,7 +208,15 @@ typedef struct fluid_create_info {
     void* hip_stream;            /* hipStream_t to enqueue on (borrowed); NULL = engine creates one  */
     void* arena;                 /* optional caller-owned device memory for all attachments          */
     uint64_t arena_bytes;        /*   (>= fluid_required_arena_bytes); NULL = engine hipMallocs      */
+    /* ---- fields added after ABI v1's first layout: read only when struct_bytes covers them ------- */
+    uint32_t surface_prep;       /* 1 = also allocate the four detailed-grid images (ids 8-11: 16 B x */
+                                 /* detailed_resolution^3 per simulation cell) and run sections      */
+                                 /* 14a-18 at the end of fluid_run_step; whole-grid contexts only     */
+    uint32_t surface_diffuse_steps; /* float_density_diffuse_steps (simulation_constants.h:127) used   */
+                                 /* by fluid_run_step(); 0 = 4                                       */
 } fluid_create_info;
+/* sizeof(fluid_create_info) before surface_prep was added: still accepted as struct_bytes */
+#define FLUID_CREATE_INFO_V1_BYTES 64
 
 /* Device bytes a context with this geometry needs (pure host arithmetic). */
 uint64_t fluid_required_arena_bytes(const fluid_create_info* info);

@@ -485,6 +485,119 @@ void oracle_14_particles(const fluid_params* p, const float* v1, float* particle
     }
 }
 
+/* ================================================================================================
+ * Surface-prep passes on the detailed grid (fluid_flow_sections.h:339-388).  The detailed grid has
+ * detailed_resolution^3 cells per simulation cell; out-of-bounds image loads return 0, stores and
+ * atomics outside the image are dropped (as everywhere else).
+ * ============================================================================================== */
+typedef struct {
+    int W, H, D, res;
+} dgrid;
+static dgrid dgrid_of(const fluid_params* p) {
+    dgrid g;
+    g.res = p->detailed_resolution;
+    g.W = (int)p->fluid_size[0] * g.res;
+    g.H = (int)p->fluid_size[1] * g.res;
+    g.D = (int)p->fluid_size[2] * g.res;
+    return g;
+}
+static uint64_t dcell(dgrid g, int x, int y, int z) {
+    return (uint64_t)x + (uint64_t)g.W * ((uint64_t)y + (uint64_t)g.H * (uint64_t)z);
+}
+static int dinside(dgrid g, int x, int y, int z) {
+    return x >= 0 && x < g.W && y >= 0 && y < g.H && z >= 0 && z < g.D;
+}
+
+/* update_detailed_densities.comp:24-31: ivec3(pos.xyz * detailed_resolution) — the int is converted to
+ * float, one fp32 product per axis, then truncation toward zero (same rule as 01_update_densities) */
+void oracle_15_update_detailed_densities(const fluid_params* p, const float* particles,
+                                         uint64_t capacity, uint32_t* detailed) {
+    dgrid g = dgrid_of(p);
+    const float fres = (float)g.res;
+    for (uint64_t i = 0; i < capacity; i++) {
+        const float* q = particles + 4 * i;
+        if (q[3] == p->active_particle_w) { /* :28 */
+            int x, y, z;
+            const float sx = q[0] * fres, sy = q[1] * fres, sz = q[2] * fres;
+            if (trunc_index(sx, g.W, &x) && trunc_index(sy, g.H, &y) && trunc_index(sz, g.D, &z))
+                detailed[dcell(g, x, y, z)] += 1u; /* :30 */
+        }
+    }
+}
+
+/* densities_inertia.comp:30-61.  GLSL mixes uint and int: `inertia += int` converts the int to uint,
+ * `inertia > inertia_decrease` and min(max_inertia, inertia) compare as uint. */
+void oracle_16_compute_detailed_densities_inertia(const fluid_params* p, const uint32_t* detailed,
+                                                  uint32_t* inertia) {
+    dgrid g = dgrid_of(p);
+    static const int mv[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
+    for (int z = 0; z < g.D; z++)
+        for (int y = 0; y < g.H; y++)
+            for (int x = 0; x < g.W; x++) {
+                const uint64_t id = dcell(g, x, y, z);
+                uint32_t in = inertia[id]; /* :38 */
+                const uint32_t old = in;
+                if (detailed[id] > 0u) in += (uint32_t)p->inertia_increase_filled; /* :42-44 */
+                int hits = 0;
+                for (int j = 0; j < 6; j++) { /* :49-52 */
+                    const int nx = x + mv[j][0], ny = y + mv[j][1], nz = z + mv[j][2];
+                    if (dinside(g, nx, ny, nz) && detailed[dcell(g, nx, ny, nz)] > 0u) hits += 1;
+                }
+                if (hits >= p->required_neighbour_hits) /* :54 */
+                    in += (uint32_t)(hits * p->inertia_increase_neighbour);
+                if (in == old) { /* :57-63 */
+                    if (in > (uint32_t)p->inertia_decrease)
+                        in -= (uint32_t)p->inertia_decrease;
+                    else
+                        in = 0u;
+                }
+                const uint32_t cap = (uint32_t)p->max_inertia; /* :65 */
+                inertia[id] = cap < in ? cap : in;
+            }
+}
+
+/* float_densities.comp:22-27: -1 where the inertia is 0, else float(inertia) / coefficient (IEEE fp32) */
+void oracle_17_compute_float_densities(const fluid_params* p, const uint32_t* inertia, float* f1) {
+    dgrid g = dgrid_of(p);
+    const uint64_t n = (uint64_t)g.W * g.H * g.D;
+    for (uint64_t i = 0; i < n; i++)
+        f1[i] = inertia[i] == 0u ? -1.0f : (float)inertia[i] / p->dens_division_coefficient;
+}
+
+/* diffuse_densities.comp:45-62 */
+static float dload(dgrid g, const float* a, int x, int y, int z) {
+    return dinside(g, x, y, z) ? a[dcell(g, x, y, z)] : 0.0f;
+}
+void oracle_18_diffuse_float_densities(const fluid_params* p, const uint8_t* types, float* f1,
+                                       float* f2, uint32_t is_even_iteration) {
+    dgrid g = dgrid_of(p);
+    grid sg = grid_of(p);
+    const float a = p->dens_diffuse_k;
+    const float* src = is_even_iteration == 1u ? f1 : f2; /* :57-61 */
+    float* dst = is_even_iteration == 1u ? f2 : f1;
+    const float k0 = 1.0f - 6.0f * a; /* ( 1.0 - 6 * dens_diffuse_a) */
+    for (int z = 0; z < g.D; z++)
+        for (int y = 0; y < g.H; y++)
+            for (int x = 0; x < g.W; x++) {
+                /* :56 the simulation cell of this detailed cell; integer division of non-negative ints */
+                const uint32_t t = types[cell(sg, x / g.res, y / g.res, z / g.res)];
+                if (t == p->cell_type_solid) continue;
+                float s = dload(g, src, x + 1, y, z) + dload(g, src, x - 1, y, z); /* :47-50 */
+                s = s + dload(g, src, x, y + 1, z);
+                s = s + dload(g, src, x, y - 1, z);
+                s = s + dload(g, src, x, y, z + 1);
+                s = s + dload(g, src, x, y, z - 1);
+                const float t1 = k0 * src[dcell(g, x, y, z)];
+                const float t2 = a * s;
+                dst[dcell(g, x, y, z)] = t1 + t2;
+            }
+}
+void oracle_18_diffuse_float_densities_loop(const fluid_params* p, const uint8_t* types, float* f1,
+                                            float* f2, uint32_t iterations) {
+    for (uint32_t k = 0; k < iterations; k++)
+        oracle_18_diffuse_float_densities(p, types, f1, f2, (k % 2u) == 0u ? 1u : 0u);
+}
+
 /* ---- section lists ----------------------------------------------------------------------------- */
 void oracle_run_init(oracle_state* s) {
     const fluid_params* p = &s->params;

@@ -65,6 +65,25 @@ void oracle_13_fix_divergence(const fluid_params* p, const uint8_t* types, const
 void oracle_14_particles(const fluid_params* p, const float* v1, float* particles,
                          uint64_t capacity);
 
+/* ---- surface-prep passes on the detailed grid: fluid_size * detailed_resolution
+ * cells per axis, x fastest, no ghost planes; images R32UI / R32UI / R32F / R32F ------------------- */
+/* 15_update_detailed_densities/update_detailed_densities.comp:24-31 */
+void oracle_15_update_detailed_densities(const fluid_params* p, const float* particles,
+                                         uint64_t capacity, uint32_t* detailed);
+/* 16_compute_detailed_densities_inertia/densities_inertia.comp:30-61 (in place on `inertia`) */
+void oracle_16_compute_detailed_densities_inertia(const fluid_params* p, const uint32_t* detailed,
+                                                  uint32_t* inertia);
+/* 17_compute_float_densities/float_densities.comp:22-27 */
+void oracle_17_compute_float_densities(const fluid_params* p, const uint32_t* inertia, float* f1);
+/* 18_diffuse_float_densities/diffuse_densities.comp:45-62: one dispatch; is_even_iteration == 1 reads f1
+ * and writes f2, else the reverse; cells whose simulation cell is SOLID are not written */
+void oracle_18_diffuse_float_densities(const fluid_params* p, const uint8_t* types, float* f1,
+                                       float* f2, uint32_t is_even_iteration);
+/* FlowLoopPushConstantSection(float_density_diffuse_steps, ... "18_diffuse_float_densities"),
+ * fluid_flow_sections.h:376-388: dispatch k has is_even_iteration = (k % 2 == 0) */
+void oracle_18_diffuse_float_densities_loop(const fluid_params* p, const uint8_t* types, float* f1,
+                                            float* f2, uint32_t iterations);
+
 /* sampler exposed for the known-answer tests: component `comp` of the trilinear sample at world
  * position (px,py,pz) as advect.comp:52-56 / particles.comp:28-36 take it */
 float oracle_sample_velocity_component(const fluid_params* p, const float* v, float px, float py,

@@ -62,6 +62,11 @@ def lib():
         "oracle_12_solve_pressure_loop": [pp, vp, vp, vp, vp, u32],
         "oracle_13_fix_divergence": [pp, vp, vp, vp],
         "oracle_14_particles": [pp, vp, vp, u64],
+        "oracle_15_update_detailed_densities": [pp, vp, u64, vp],
+        "oracle_16_compute_detailed_densities_inertia": [pp, vp, vp],
+        "oracle_17_compute_float_densities": [pp, vp, vp],
+        "oracle_18_diffuse_float_densities": [pp, vp, vp, vp, u32],
+        "oracle_18_diffuse_float_densities_loop": [pp, vp, vp, vp, u32],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -83,7 +88,9 @@ class OracleState:
     [z][y][x] C order == x fastest) plus one method per section."""
 
     def __init__(self, params: FluidParams, particle_capacity: int, pressure_iterations: int = 200,
-                 diffuse_mode: int = 0):
+                 diffuse_mode: int = 0, surface_prep: bool = False, surface_diffuse_steps: int = 4):
+        self.surface_prep = bool(surface_prep)
+        self.surface_diffuse_steps = int(surface_diffuse_steps)
         self.params = params.copy()
         self.capacity = int(particle_capacity)
         self.pressure_iterations = int(pressure_iterations)
@@ -100,13 +107,24 @@ class OracleState:
         self.particle_densities = np.zeros(self.shape, np.uint32)
         self.particles = np.zeros((self.capacity, 4), np.float32)
         self._p = C.byref(self.params)
+        if self.surface_prep:  # the detailed grid of sections 15-18 (images 8..11)
+            r = int(params.detailed_resolution)
+            self.detailed_shape = (d * r, h * r, w * r)
+            self.detailed_densities = np.zeros(self.detailed_shape, np.uint32)
+            self.detailed_densities_inertia = np.zeros(self.detailed_shape, np.uint32)
+            self.float_densities_1 = np.zeros(self.detailed_shape, np.float32)
+            self.float_densities_2 = np.zeros(self.detailed_shape, np.float32)
 
     FIELDS = ["velocities_1", "velocities_2", "cell_types", "new_cell_types", "pressures_1",
               "pressures_2", "divergences", "particle_densities", "particles"]
 
+    SURFACE_FIELDS = ["detailed_densities", "detailed_densities_inertia", "float_densities_1",
+                      "float_densities_2"]
+
     def copy(self) -> "OracleState":
-        o = OracleState(self.params, self.capacity, self.pressure_iterations, self.diffuse_mode)
-        for f in self.FIELDS:
+        o = OracleState(self.params, self.capacity, self.pressure_iterations, self.diffuse_mode,
+                        self.surface_prep, self.surface_diffuse_steps)
+        for f in self.FIELDS + (self.SURFACE_FIELDS if self.surface_prep else []):
             getattr(o, f)[...] = getattr(self, f)
         return o
 
@@ -159,8 +177,41 @@ class OracleState:
                                        _ptr(self.velocities_1))
         elif name == "14_particles":
             L.oracle_14_particles(p, _ptr(self.velocities_1), _ptr(self.particles), self.capacity)
+        elif name == "init_clear_detailed_densities_inertia":
+            self.detailed_densities_inertia[...] = 0
+        elif name == "14a_clear_detailed_densities":
+            self.detailed_densities[...] = 0
+        elif name == "15_update_detailed_densities":
+            L.oracle_15_update_detailed_densities(p, _ptr(self.particles), self.capacity,
+                                                  _ptr(self.detailed_densities))
+        elif name == "16_compute_detailed_densities_inertia":
+            L.oracle_16_compute_detailed_densities_inertia(p, _ptr(self.detailed_densities),
+                                                           _ptr(self.detailed_densities_inertia))
+        elif name == "17_compute_float_densities":
+            self._surface_dispatch = 0
+            L.oracle_17_compute_float_densities(p, _ptr(self.detailed_densities_inertia),
+                                                _ptr(self.float_densities_1))
+        elif name == "18_diffuse_float_densities":  # one dispatch; the counter restarts at 17
+            k = getattr(self, "_surface_dispatch", 0)
+            self._surface_dispatch = k + 1
+            L.oracle_18_diffuse_float_densities(p, _ptr(self.cell_types), _ptr(self.float_densities_1),
+                                                _ptr(self.float_densities_2), 1 if k % 2 == 0 else 0)
         else:
             raise KeyError(name)
+
+    def diffuse_float_densities(self, iterations: int):
+        self._surface_dispatch = iterations
+        lib().oracle_18_diffuse_float_densities_loop(self._p, _ptr(self.cell_types),
+                                                     _ptr(self.float_densities_1),
+                                                     _ptr(self.float_densities_2), iterations)
+
+    SURFACE_ORDER = ["14a_clear_detailed_densities", "15_update_detailed_densities",
+                     "16_compute_detailed_densities_inertia", "17_compute_float_densities"]
+
+    def run_surface_prep(self):
+        for s in self.SURFACE_ORDER:
+            self.run_section(s)
+        self.diffuse_float_densities(self.surface_diffuse_steps)
 
     def pressure_dispatch(self, is_even_iteration: int):
         lib().oracle_12_solve_pressure(self._p, _ptr(self.cell_types), _ptr(self.divergences),
@@ -183,6 +234,8 @@ class OracleState:
     def run_init(self):
         for s in self.INIT_ORDER:
             self.run_section(s)
+            if s == "init_clear_cell_types" and self.surface_prep:
+                self.run_section("init_clear_detailed_densities_inertia")
 
     def run_step(self):
         for s in self.STEP_BEFORE_12:
@@ -190,6 +243,8 @@ class OracleState:
         self.solve_pressure(self.pressure_iterations)
         for s in self.STEP_AFTER_12:
             self.run_section(s)
+        if self.surface_prep:
+            self.run_surface_prep()
 
     def sample(self, field: np.ndarray, px: float, py: float, pz: float, comp: int) -> float:
         return float(lib().oracle_sample_velocity_component(self._p, _ptr(field), px, py, pz, comp))

@@ -1,0 +1,116 @@
+"""Parity of the surface-prep passes 15-18 (detailed grid, images 8..11) against the oracle, through the
+C ABI.  Bit-exact, like everything else."""
+import numpy as np
+import pytest
+
+import fluid_amd
+from fluid_amd import engine as E
+from fluid_amd.params import CELL_SOLID, dam_break_params
+from helpers import assert_bit_equal, assert_state_equal, random_state, upload_state
+from oracle_binding import OracleState
+
+pytestmark = pytest.mark.gpu
+
+SURFACE_IMAGES = {"detailed_densities": E.DETAILED_DENSITIES_IMG,
+                  "detailed_densities_inertia": E.DETAILED_DENSITIES_INERTIA_IMG,
+                  "float_densities_1": E.PARTICLE_DENSITIES_FLOAT_1,
+                  "float_densities_2": E.PARTICLE_DENSITIES_FLOAT_2}
+
+
+def surface_state(size, res, seed, cap=3000):
+    base = random_state(size, capacity=cap, seed=seed)
+    base.params.detailed_resolution = res
+    st = OracleState(base.params, cap, 4, surface_prep=True)
+    for f in OracleState.FIELDS:
+        getattr(st, f)[...] = getattr(base, f)
+    rng = np.random.default_rng(seed)
+    st.detailed_densities[...] = rng.integers(0, 2, st.detailed_shape) * rng.integers(0, 3, st.detailed_shape)
+    st.detailed_densities_inertia[...] = rng.integers(0, 120, st.detailed_shape)
+    st.float_densities_1[...] = rng.uniform(-1, 3, st.detailed_shape).astype(np.float32)
+    st.float_densities_2[...] = rng.uniform(-1, 3, st.detailed_shape).astype(np.float32)
+    return st
+
+
+def engine_for(st):
+    eng = fluid_amd.FluidEngine(st.params, particle_capacity=st.capacity, pressure_iterations=4,
+                                surface_prep=True, surface_diffuse_steps=st.surface_diffuse_steps)
+    upload_state(eng, st)
+    for f, img in SURFACE_IMAGES.items():
+        eng.upload_image(img, getattr(st, f))
+    return eng
+
+
+def assert_surface_equal(eng, st, ctx):
+    for f, img in SURFACE_IMAGES.items():
+        assert_bit_equal(eng.download_image(img), getattr(st, f), f"{ctx}{f}")
+
+
+@pytest.mark.parametrize("size,res", [((12, 9, 7), 5), ((16, 5, 4), 3), ((7, 6, 5), 1), ((33, 3, 2), 2)])
+@pytest.mark.parametrize("section", ["14a_clear_detailed_densities", "15_update_detailed_densities",
+                                     "16_compute_detailed_densities_inertia",
+                                     "17_compute_float_densities", "18_diffuse_float_densities",
+                                     "init_clear_detailed_densities_inertia"])
+def test_surface_section_matches_oracle(section, size, res):
+    st = surface_state(size, res, seed=len(section) + size[0])
+    with engine_for(st) as eng:
+        eng.run_section(section)
+        st.run_section(section)
+        if section == "18_diffuse_float_densities":   # the second dispatch goes the other way
+            eng.run_section(section)
+            st.run_section(section)
+        assert_surface_equal(eng, st, f"{section} {size} x{res}: ")
+        assert_state_equal(eng, st, ctx="the simulation images are untouched: ")
+
+
+def test_surface_loop_and_inertia_parameters():
+    st = surface_state((10, 8, 6), 4, seed=2)
+    st.params.required_neighbour_hits = 2
+    st.params.inertia_increase_neighbour = 3
+    st.params.inertia_decrease = 7
+    st.params.max_inertia = 90
+    st.params.dens_diffuse_k = 0.13
+    with engine_for(st) as eng:
+        for s in ("16_compute_detailed_densities_inertia", "17_compute_float_densities"):
+            eng.run_section(s)
+            st.run_section(s)
+        eng.run_section_loop("18_diffuse_float_densities", 5)
+        st.diffuse_float_densities(5)
+        assert_surface_equal(eng, st, "loop x5: ")
+
+
+def test_full_step_with_surface_prep_matches_oracle():
+    """fluid_run_init / fluid_run_step of a surface_prep context = the reference's complete section
+    lists (fluid_flow_sections.h:139-154, 163-388) up to the renderer."""
+    size, iters = (24, 20, 16), 8
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters, surface_prep=True)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters,
+                               surface_prep=True) as eng:
+        # the inertia image starts dirty: the init list clears it (:142)
+        eng.upload_image(E.DETAILED_DENSITIES_INERTIA_IMG,
+                         np.full(eng.detailed_shape, 17, np.uint32))
+        eng.run_init()
+        st.run_init()
+        for k in range(4):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"step {k}: ")
+            assert_surface_equal(eng, st, f"step {k}: ")
+        assert np.count_nonzero(st.detailed_densities) > 100 and np.any(st.float_densities_1 != -1.0)
+        times = None
+        eng.enable_timing(True)
+        eng.run_step()
+        times = eng.section_times()
+        assert times["18_diffuse_float_densities"][1] == 4 and times["15_update_detailed_densities"][1] == 1
+
+
+def test_surface_images_need_a_surface_context():
+    p, cap = dam_break_params(16, 16, 16)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap) as eng:
+        with pytest.raises(fluid_amd.FluidEngineError, match="surface_prep"):
+            eng.run_section("15_update_detailed_densities")
+        with pytest.raises(fluid_amd.FluidEngineError) as ei:
+            eng.download_image(E.PARTICLE_DENSITIES_FLOAT_1)
+        assert ei.value.code == E.ERR_UNSUPPORTED
+    with pytest.raises(fluid_amd.FluidEngineError):   # not on a Z slab
+        fluid_amd.FluidEngine(p, particle_capacity=cap, slab=(0, 8), surface_prep=True)

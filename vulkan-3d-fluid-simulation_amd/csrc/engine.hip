@@ -20,6 +20,7 @@
 #include "pressure_api.h"
 #include "kernels_sampler.h"
 #include "kernels_step_fused.h"
+#include "kernels_surface.h"
 
 static_assert(sizeof(fluid_params) == FLUID_PARAMS_BYTES, "params block must be 264 bytes");
 static_assert(offsetof(fluid_params, particle_compute_size) == 48, "std140 offset");
@@ -79,6 +80,18 @@ struct fluid_ctx {
 
     ImageDesc img[8];
     int64_t opt[FLUID_OPT_COUNT] = {0};
+
+    // surface-prep passes 15-18 on the detailed grid (kernels_surface.h); images 8..11
+    bool surface = false;
+    SurfK sk{};
+    uint64_t surf_cells = 0;
+    uint64_t surf_offset[4] = {0, 0, 0, 0};
+    uint32_t surface_steps = 4;
+    uint32_t surface_dispatch_index = 0;  // loop counter of the 18_diffuse_float_densities section
+    template <typename T>
+    T* surf(int image_id) const {
+        return reinterpret_cast<T*>(arena + surf_offset[image_id - 8]);
+    }
 
     // loop-section fast path of 12_solve_pressure (kernels_pressure.h / kernels_pressure_fused.h)
     uint64_t mask_offset = 0, rhs_offset = 0;  // per-cell byte mask / b_i, Dl + 2*LOOP_GHOST planes
@@ -247,8 +260,15 @@ struct Layout {
         pbricks_offset, work_offset[3];
     uint64_t flags_offset, leavers_offset;
     uint32_t leavers_capacity;
+    uint64_t surf_offset[4], surf_cells;
     uint64_t total;
 };
+
+bool info_has(const fluid_create_info* info, size_t field_end) { return info->struct_bytes >= field_end; }
+bool wants_surface(const fluid_create_info* info) {
+    return info_has(info, offsetof(fluid_create_info, surface_prep) + sizeof(uint32_t)) &&
+           info->surface_prep != 0;
+}
 
 int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout& L,
                    uint64_t& capacity, uint32_t& z0, uint32_t& dl) {
@@ -302,6 +322,17 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
         slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(capacity / 4, 65536), 0x7FFFFFFFu) : 0;
     L.leavers_offset = off;
     off = align_up(off + (uint64_t)L.leavers_capacity * sizeof(Leaver), kAlign);
+    L.surf_cells = 0;
+    for (int i = 0; i < 4; i++) L.surf_offset[i] = 0;
+    if (wants_surface(info)) {
+        if (slab || p.detailed_resolution < 1) return FLUID_ERR_INVALID_ARG;
+        const uint64_t r = (uint64_t)p.detailed_resolution;
+        L.surf_cells = (r * p.fluid_size[0]) * (r * p.fluid_size[1]) * (r * p.fluid_size[2]);
+        for (int i = 0; i < 4; i++) {
+            L.surf_offset[i] = off;
+            off = align_up(off + L.surf_cells * 4, kAlign);
+        }
+    }
     L.total = std::max<uint64_t>(off, kAlign);
     return FLUID_OK;
 }
@@ -360,9 +391,10 @@ struct SectionTimer {
 // Fill the OWNED planes of an image with one texel value (FlowClearColorSection).  `v` holds the
 // texel as 32-bit words: 4 for RGBA32F, 1 for R32*, low byte of v[0] for R8.
 int fill_image4(fluid_ctx* c, int image, const uint32_t v[4]) {
-    const uint32_t eb = c->img[image].elem_bytes;
-    const uint64_t bytes = c->owned_cells() * eb;
-    uint8_t* dst = c->plane0<uint8_t>(image);
+    // images 8..11 live on the detailed grid (4-byte texels, no ghost planes)
+    const uint32_t eb = image >= 8 ? 4u : c->img[image].elem_bytes;
+    const uint64_t bytes = image >= 8 ? c->surf_cells * 4 : c->owned_cells() * eb;
+    uint8_t* dst = image >= 8 ? c->surf<uint8_t>(image) : c->plane0<uint8_t>(image);
     uint4 pat;
     if (eb == 16)
         pat = make_uint4(v[0], v[1], v[2], v[3]);
@@ -843,6 +875,53 @@ int run_section_impl(fluid_ctx* c, int section) {
                                bk, qchunks);
             c->v1_w_zero = true;
             break;
+        // ---- surface-prep passes (kernels_surface.h)
+        case FLUID_SEC_INIT_CLEAR_DETAILED_DENSITIES_INERTIA:
+        case FLUID_SEC_14A_CLEAR_DETAILED_DENSITIES:
+        case FLUID_SEC_15_UPDATE_DETAILED_DENSITIES:
+        case FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA:
+        case FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES:
+        case FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES: {
+            if (!c->surface)
+                return c->fail(FLUID_ERR_UNSUPPORTED,
+                               "section %d is a surface-prep pass: create the context with "
+                               "fluid_create_info.surface_prep", section);
+            const SurfK& s = c->sk;
+            const dim3 sgrid((s.W + 63) / 64, (s.H + 3) / 4, s.D);
+            uint32_t* det = c->surf<uint32_t>(FLUID_IMG_DETAILED_DENSITIES_IMG);
+            uint32_t* inertia = c->surf<uint32_t>(FLUID_IMG_DETAILED_DENSITIES_INERTIA_IMG);
+            float* f1 = c->surf<float>(FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1);
+            float* f2 = c->surf<float>(FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2);
+            if (section == FLUID_SEC_INIT_CLEAR_DETAILED_DENSITIES_INERTIA)
+                return fill_image(c, FLUID_IMG_DETAILED_DENSITIES_INERTIA_IMG, 0u);
+            if (section == FLUID_SEC_14A_CLEAR_DETAILED_DENSITIES)
+                return fill_image(c, FLUID_IMG_DETAILED_DENSITIES_IMG, 0u);
+            if (section == FLUID_SEC_15_UPDATE_DETAILED_DENSITIES) {
+                if (c->particle_capacity == 0) return FLUID_OK;
+                hipLaunchKernelGGL(k15_update_detailed_densities, dim3(pblocks), dim3(256), 0, c->stream,
+                                   c->particles(), c->particle_capacity, det, s, pk.active_w);
+            } else if (section == FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA) {
+                InertiaK k;
+                k.max_inertia = (uint32_t)c->params.max_inertia;
+                k.increase_filled = (uint32_t)c->params.inertia_increase_filled;
+                k.increase_neighbour = (uint32_t)c->params.inertia_increase_neighbour;
+                k.decrease = (uint32_t)c->params.inertia_decrease;
+                k.required_hits = c->params.required_neighbour_hits;
+                k.increase_neighbour_i = c->params.inertia_increase_neighbour;
+                hipLaunchKernelGGL(k16_detailed_densities_inertia, sgrid, block, 0, c->stream, det,
+                                   inertia, s, k);
+            } else if (section == FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES) {
+                c->surface_dispatch_index = 0;
+                hipLaunchKernelGGL(k17_float_densities, sgrid, block, 0, c->stream, inertia, f1, s,
+                                   c->params.dens_division_coefficient);
+            } else {  // one dispatch of the 18 loop; even dispatches read FLOAT_1 and write FLOAT_2
+                const bool even = (c->surface_dispatch_index % 2u) == 0u;
+                c->surface_dispatch_index++;
+                hipLaunchKernelGGL(k18_diffuse_float_densities, sgrid, block, 0, c->stream, T,
+                                   even ? f1 : f2, even ? f2 : f1, s, c->params.dens_diffuse_k, pk.t_solid);
+            }
+            break;
+        }
         case FLUID_SEC_14_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
             hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
@@ -870,12 +949,19 @@ int timed_section(fluid_ctx* c, int section, int impl = -1) {
 int check_image(fluid_ctx* c, int image_id) {
     if (image_id < 0 || image_id >= FLUID_IMAGE_COUNT)
         return c->fail(FLUID_ERR_INVALID_ARG, "unknown image id %d", image_id);
-    if (image_id >= 8)
+    if (image_id >= 8 && !c->surface)
         return c->fail(FLUID_ERR_UNSUPPORTED,
-                       "image %d belongs to the surface-render path (sections 15-18), which this "
-                       "engine does not implement",
+                       "image %d belongs to the surface-prep passes (sections 15-18): create the context "
+                       "with fluid_create_info.surface_prep",
                        image_id);
     return FLUID_OK;
+}
+// bytes of the part of an image that upload / download / clear address
+uint64_t image_host_bytes(const fluid_ctx* c, int image_id) {
+    return image_id >= 8 ? c->surf_cells * 4 : c->owned_cells() * c->img[image_id].elem_bytes;
+}
+uint8_t* image_host_base(const fluid_ctx* c, int image_id) {
+    return image_id >= 8 ? c->surf<uint8_t>(image_id) : c->plane0<uint8_t>(image_id);
 }
 
 }  // namespace
@@ -959,7 +1045,7 @@ uint64_t fluid_required_arena_bytes(const fluid_create_info* info) {
 }
 
 int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
-    if (!out || !info || !info->params_blob || info->struct_bytes < sizeof(fluid_create_info)) {
+    if (!out || !info || !info->params_blob || info->struct_bytes < FLUID_CREATE_INFO_V1_BYTES) {
         g_create_error = "fluid_create: null argument or struct_bytes too small";
         return FLUID_ERR_INVALID_ARG;
     }
@@ -973,7 +1059,8 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     uint32_t z0, dl;
     rc = compute_layout(info, p, L, capacity, z0, dl);
     if (rc) {
-        g_create_error = "slab_z_begin + slab_z_count exceeds fluid_size.z";
+        g_create_error = "slab_z_begin + slab_z_count exceeds fluid_size.z, or surface_prep on a Z-slab "
+                         "context / with detailed_resolution < 1";
         return rc;
     }
 
@@ -1008,6 +1095,21 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->g.plane = (int64_t)p.fluid_size[0] * p.fluid_size[1];
     c->is_slab = dl != p.fluid_size[2];
     c->particle_capacity = capacity;
+    c->surface = L.surf_cells != 0;
+    if (c->surface) {
+        c->sk.res = p.detailed_resolution;
+        c->sk.W = c->g.W * c->sk.res;
+        c->sk.H = c->g.H * c->sk.res;
+        c->sk.D = c->g.Dg * c->sk.res;
+        c->sk.sW = c->g.W;
+        c->sk.sH = c->g.H;
+        c->sk.plane = (int64_t)c->sk.W * c->sk.H;
+        c->surf_cells = L.surf_cells;
+        for (int i = 0; i < 4; i++) c->surf_offset[i] = L.surf_offset[i];
+        if (info_has(info, offsetof(fluid_create_info, surface_diffuse_steps) + sizeof(uint32_t)) &&
+            info->surface_diffuse_steps != 0)
+            c->surface_steps = info->surface_diffuse_steps;
+    }
     c->pressure_iterations = info->pressure_iterations ? info->pressure_iterations : 200;
     for (int i = 0; i < 8; i++) {
         c->img[i].elem_bytes = kElemBytes[i];
@@ -1091,8 +1193,8 @@ const char* fluid_last_error(const fluid_ctx* c) {
 int fluid_image_bytes(const fluid_ctx* c, int image_id, uint64_t* bytes) {
     if (!c || !bytes) return FLUID_ERR_INVALID_ARG;
     if (image_id < 0 || image_id >= FLUID_IMAGE_COUNT) return FLUID_ERR_INVALID_ARG;
-    if (image_id >= 8) return FLUID_ERR_UNSUPPORTED;
-    *bytes = c->owned_cells() * c->img[image_id].elem_bytes;
+    if (image_id >= 8 && !c->surface) return FLUID_ERR_UNSUPPORTED;
+    *bytes = image_host_bytes(c, image_id);
     return FLUID_OK;
 }
 
@@ -1119,13 +1221,13 @@ int fluid_upload_image(fluid_ctx* c, int image_id, const void* host, uint64_t by
     int rc = check_image(c, image_id);
     if (rc) return rc;
     if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
-    const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
+    const uint64_t want = image_host_bytes(c, image_id);
     if (bytes != want)
         return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
                        image_id, (unsigned long long)want, (unsigned long long)bytes);
     HIP_TRY(c, hipSetDevice(c->device));
     c->touched(image_id);
-    HIP_TRY(c, hipMemcpyAsync(c->plane0<uint8_t>(image_id), host, bytes, hipMemcpyHostToDevice,
+    HIP_TRY(c, hipMemcpyAsync(image_host_base(c, image_id), host, bytes, hipMemcpyHostToDevice,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FLUID_OK;
@@ -1136,12 +1238,12 @@ int fluid_download_image(fluid_ctx* c, int image_id, void* host, uint64_t bytes)
     int rc = check_image(c, image_id);
     if (rc) return rc;
     if (!host) return c->fail(FLUID_ERR_INVALID_ARG, "null host pointer");
-    const uint64_t want = c->owned_cells() * c->img[image_id].elem_bytes;
+    const uint64_t want = image_host_bytes(c, image_id);
     if (bytes != want)
         return c->fail(FLUID_ERR_SIZE_MISMATCH, "image %d holds %llu bytes, caller passed %llu",
                        image_id, (unsigned long long)want, (unsigned long long)bytes);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(host, c->plane0<uint8_t>(image_id), bytes, hipMemcpyDeviceToHost,
+    HIP_TRY(c, hipMemcpyAsync(host, image_host_base(c, image_id), bytes, hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FLUID_OK;
@@ -1375,9 +1477,20 @@ int fluid_pressure_loop_plane_ptr(fluid_ctx* c, int which, int32_t plane, void**
 
 int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
     if (!c) return FLUID_ERR_INVALID_ARG;
+    if (section_id == FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES) {
+        // FlowLoopPushConstantSection(float_density_diffuse_steps, ...), fluid_flow_sections.h:376-388
+        HIP_TRY(c, hipSetDevice(c->device));
+        c->surface_dispatch_index = 0;
+        for (uint32_t k = 0; k < iterations; k++) {
+            int rc = timed_section(c, section_id);
+            if (rc) return rc;
+        }
+        return FLUID_OK;
+    }
     if (section_id != FLUID_SEC_12_SOLVE_PRESSURE)
         return c->fail(FLUID_ERR_INVALID_ARG,
-                       "section %d is not a loop section (only 12_solve_pressure is)", section_id);
+                       "section %d is not a loop section (12_solve_pressure and "
+                       "18_diffuse_float_densities are)", section_id);
     HIP_TRY(c, hipSetDevice(c->device));
     // FlowLoopPushConstantSection (fluid_flow_sections.h:300-313): the loop owns its own counter —
     // dispatch k of this call has is_even_iteration = (k % 2 == 0).
@@ -1406,8 +1519,25 @@ int fluid_run_init(fluid_ctx* c) {
     for (int s : order) {
         int rc = timed_section(c, s);
         if (rc) return rc;
+        if (s == FLUID_SEC_INIT_CLEAR_CELL_TYPES && c->surface) {  // list order, :140-143
+            rc = timed_section(c, FLUID_SEC_INIT_CLEAR_DETAILED_DENSITIES_INERTIA);
+            if (rc) return rc;
+        }
     }
     return FLUID_OK;
+}
+
+// fluid_flow_sections.h:339-388: the tail of SimulationStepSections on the detailed grid
+static int run_surface_prep(fluid_ctx* c) {
+    static const int order[] = {FLUID_SEC_14A_CLEAR_DETAILED_DENSITIES,
+                                FLUID_SEC_15_UPDATE_DETAILED_DENSITIES,
+                                FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA,
+                                FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES};
+    for (int s : order) {
+        int rc = timed_section(c, s);
+        if (rc) return rc;
+    }
+    return fluid_run_section_loop(c, FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES, c->surface_steps);
 }
 
 // Entries [first, first + count) of SimulationStepSections (fluid_flow_sections.h:163-338; the ids are
@@ -1488,9 +1618,11 @@ int fluid_run_step(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->is_slab) return slab_unsupported(c, "fluid_run_step");
-    return run_step_slice(c, FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES,
-                          FLUID_SEC_14_PARTICLES - FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES + 1,
-                          c->opt[FLUID_OPT_STEP_FUSION] == 0, true);
+    int rc = run_step_slice(c, FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES,
+                            FLUID_SEC_14_PARTICLES - FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES + 1,
+                            c->opt[FLUID_OPT_STEP_FUSION] == 0, true);
+    if (rc == FLUID_OK && c->surface) rc = run_surface_prep(c);
+    return rc;
 }
 
 int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) {
@@ -1560,6 +1692,13 @@ int fluid_image_plane_ptr(fluid_ctx* c, int image_id, int32_t plane, void** devi
     if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
     int rc = check_image(c, image_id);
     if (rc) return rc;
+    if (image_id >= 8) {  // detailed grid: planes of W*H*res^2 texels, no ghost planes
+        if (plane < 0 || plane >= c->sk.D)
+            return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [0, %d)", plane, c->sk.D);
+        *bytes = (uint64_t)c->sk.plane * 4;
+        *device_ptr = c->surf<uint8_t>(image_id) + (uint64_t)plane * *bytes;
+        return FLUID_OK;
+    }
     if (plane < -IMG_GHOST || plane >= c->g.Dl + IMG_GHOST)
         return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -IMG_GHOST,
                        c->g.Dl + IMG_GHOST);

@@ -31,6 +31,11 @@ IMAGE_DTYPES = {
     PRESSURES_1: (np.float32, 1), PRESSURES_2: (np.float32, 1), DIVERGENCES: (np.float32, 1),
     PARTICLE_DENSITIES_IMG: (np.uint32, 1),
 }
+# images on the detailed grid (contexts created with surface_prep=True)
+SURFACE_DTYPES = {
+    DETAILED_DENSITIES_IMG: np.uint32, DETAILED_DENSITIES_INERTIA_IMG: np.uint32,
+    PARTICLE_DENSITIES_FLOAT_1: np.float32, PARTICLE_DENSITIES_FLOAT_2: np.float32,
+}
 
 SECTION_NAMES = [
     "init_clear_velocities_1", "init_clear_cell_types", "00_init_particles",
@@ -39,6 +44,10 @@ SECTION_NAMES = [
     "07_advect", "08_forces", "09_diffuse", "10_solids", "11_compute_divergence",
     "12a_clear_pressures_1", "12b_clear_pressures_2", "12_solve_pressure", "13_fix_divergence",
     "14_particles",
+    # surface-prep passes (surface_prep contexts)
+    "14a_clear_detailed_densities", "15_update_detailed_densities",
+    "16_compute_detailed_densities_inertia", "17_compute_float_densities",
+    "18_diffuse_float_densities", "init_clear_detailed_densities_inertia",
 ]
 SECTION_IDS = {name: i for i, name in enumerate(SECTION_NAMES)}
 SEC_12_SOLVE_PRESSURE = SECTION_IDS["12_solve_pressure"]
@@ -86,6 +95,8 @@ class CreateInfo(C.Structure):
         ("hip_stream", C.c_void_p),
         ("arena", C.c_void_p),
         ("arena_bytes", C.c_uint64),
+        ("surface_prep", C.c_uint32),
+        ("surface_diffuse_steps", C.c_uint32),
     ]
 
 
@@ -179,8 +190,10 @@ class FluidEngine:
     def __init__(self, params: FluidParams, particle_capacity: int = 0,
                  pressure_iterations: int = 200, device: int = -1,
                  slab: Optional[tuple] = None, stream: int = 0, arena: int = 0,
-                 arena_bytes: int = 0, lib_path: Optional[str] = None):
+                 arena_bytes: int = 0, lib_path: Optional[str] = None,
+                 surface_prep: bool = False, surface_diffuse_steps: int = 0):
         self._lib = load_library(lib_path)
+        self.surface_prep = bool(surface_prep)
         self._h = C.c_void_p()
         self._blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
         info = CreateInfo()
@@ -194,6 +207,8 @@ class FluidEngine:
         info.hip_stream = stream or None
         info.arena = arena or None
         info.arena_bytes = arena_bytes
+        info.surface_prep = 1 if surface_prep else 0
+        info.surface_diffuse_steps = surface_diffuse_steps
         rc = self._lib.fluid_create(C.byref(self._h), C.byref(info))
         if rc != OK:
             msg = self._lib.fluid_last_error(None)
@@ -250,13 +265,22 @@ class FluidEngine:
         return (self.slab_z_count, h, w)
 
     # -- data movement --------------------------------------------------------------------------
+    @property
+    def detailed_shape(self):
+        """(D, H, W) of the detailed grid of the surface-prep passes."""
+        r = int(self.params.detailed_resolution)
+        w, h, d = self.global_size
+        return (d * r, h * r, w * r)
+
     def image_shape(self, image_id: int):
+        if image_id in SURFACE_DTYPES:
+            return SURFACE_DTYPES[image_id], self.detailed_shape
         dtype, ch = IMAGE_DTYPES[image_id]
         shape = self.local_shape + ((ch,) if ch > 1 else ())
         return dtype, shape
 
     def upload_image(self, image_id: int, array: np.ndarray):
-        if image_id in IMAGE_DTYPES:
+        if image_id in IMAGE_DTYPES or (image_id in SURFACE_DTYPES and self.surface_prep):
             dtype, shape = self.image_shape(image_id)
             array = np.ascontiguousarray(array, dtype=dtype)
             if array.size != int(np.prod(shape)):
@@ -268,7 +292,7 @@ class FluidEngine:
                                                  array.nbytes))
 
     def download_image(self, image_id: int) -> np.ndarray:
-        if image_id not in IMAGE_DTYPES:
+        if image_id not in IMAGE_DTYPES and not (image_id in SURFACE_DTYPES and self.surface_prep):
             self._check(self._lib.fluid_download_image(self._h, image_id, None, 0))
         dtype, shape = self.image_shape(image_id)
         out = np.empty(shape, dtype=dtype)
