@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--full-step-steps", type=int, default=20)
+    ap.add_argument("--no-surface", action="store_true",
+                    help="skip the surface-prep figure (128^3 + 640^3 detailed grid, 4.3 GB)")
     return ap.parse_args()
 
 
@@ -222,6 +224,41 @@ def full_step_bench(size, iters, steps, device):
         "note": ("grouped passes: 04/05 = the two type scans of 04+05, 07 = 07+08, 09 = 09+10+11; "
                  "12_solve_pressure includes its prepare / import / export passes"),
     }
+
+
+def surface_prep_bench(n, iters, device):
+    """The surface-prep tail of the reference's step list (sections 14a, 15-18 on the detailed grid,
+    SURVEY.md 8f N3) on the dam-break scene: n^3 simulation cells, (5n)^3 detailed cells."""
+    import fluid_amd
+
+    p, cap = fluid_amd.dam_break_params(n, n, n)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters, device=device,
+                               surface_prep=True) as eng:
+        eng.run_init()
+        for _ in range(4):
+            eng.run_step()
+        eng.sync()
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run_step()
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        eng.enable_timing(True)
+        eng.reset_timing()
+        for _ in range(3):
+            eng.run_step()
+        eng.sync()
+        times = {k: v[0] / 3 for k, v in eng.section_times().items() if v[1]}
+        d = eng.detailed_shape
+    cells = d[0] * d[1] * d[2]
+    tail = sum(v for k, v in times.items() if k[:3] in ("14a", "15_", "16_", "17_", "18_"))
+    # clear 4 + 16: R 4+4 W 4 + 17: R 4 W 4 + 18: (R 4 + W 4) x 4 dispatches = 56 B per detailed cell
+    return {"workload": f"dam-break {n}^3 + detailed grid {d[2]}x{d[1]}x{d[0]}, {iters} Jacobi iters",
+            "steps_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "surface_tail_ms": tail,
+            "surface_tail_algorithmic_GBps": 56.0 * cells / (tail * 1e-3) / 1e9,
+            "section_ms": {k: round(v, 4) for k, v in times.items()
+                           if k[:3] in ("14a", "15_", "16_", "17_", "18_")}}
 
 
 def slab_full_step_bench(size, iters, steps, dist_ctx, overlap=None):
@@ -420,6 +457,11 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     if not args.no_full_step:
         out["full_step"] = full_step_bench(size, args.iters, args.full_step_steps, local_rank)
+    if not args.no_surface and not args.no_full_step:
+        try:
+            out["surface_prep"] = surface_prep_bench(128, 80, local_rank)
+        except Exception as exc:  # secondary figure
+            out["surface_prep"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(out), flush=True)
 
 

@@ -7,6 +7,7 @@
  *
  *   SimulationInitializationSections   fluid_flow_sections.h:136-156   -> fluid_run_init()
  *   SimulationStepSections (01a … 14)  fluid_flow_sections.h:159-338   -> fluid_run_step()
+ *     … and its tail 15 … 18 (:339-388, surface-prep passes) on contexts created with surface_prep
  *   one Flow*Section of those lists                                    -> fluid_run_section()
  *   FlowLoopPushConstantSection<…>(N, "12_solve_pressure")  :300-313   -> fluid_run_section_loop()
  *   ImageAttachments / BufferAttachments enums              :10-16     -> fluid_image_id / fluid_buffer_id
@@ -255,7 +256,8 @@ int fluid_run_section(fluid_ctx* ctx, int section_id);
 /* FlowLoopPushConstantSection<FlowComputePushConstantSection>(iterations, …) of
  * fluid_flow_sections.h:300-313: `iterations` dispatches, dispatch k has is_even_iteration =
  * (k % 2 == 0), i.e. reads PRESSURES_1 / writes PRESSURES_2 on even k (pressure.comp:28-31,71-75;
- * SURVEY.md F2).  Only FLUID_SEC_12_SOLVE_PRESSURE is a loop section on this path. */
+ * SURVEY.md F2).  Loop sections: FLUID_SEC_12_SOLVE_PRESSURE and, on surface_prep contexts,
+ * FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES (:376-388, float_density_diffuse_steps dispatches). */
 int fluid_run_section_loop(fluid_ctx* ctx, int section_id, uint32_t iterations);
 
 /* `count` consecutive entries of SimulationStepSections, starting at `first_section_id`, as one unit
@@ -284,9 +286,15 @@ int fluid_clear_image(fluid_ctx* ctx, int image_id, const uint32_t value_bits[4]
 /* One 12_solve_pressure dispatch with an explicit push constant (pressure.comp:29-31). */
 int fluid_run_pressure_dispatch(fluid_ctx* ctx, uint32_t is_even_iteration);
 
+/* One 18_diffuse_float_densities dispatch with an explicit push constant (diffuse_densities.comp:38-40):
+ * 1 reads PARTICLE_DENSITIES_FLOAT_1 and writes _2, 0 the reverse.  surface_prep contexts. */
+int fluid_run_surface_diffuse_dispatch(fluid_ctx* ctx, uint32_t is_even_iteration);
+
 /* SimulationInitializationSections::run (fluid_flow_sections.h:139-154; main.cpp:111). */
 int fluid_run_init(fluid_ctx* ctx);
-/* SimulationStepSections::run restricted to 01a…14 (fluid_flow_sections.h:163-338; main.cpp:172). */
+/* SimulationStepSections::run (main.cpp:172): 01a…14 (fluid_flow_sections.h:163-338) and, on a
+ * surface_prep context, the rest of the list up to the renderer: the detailed-density clear and 15…18
+ * (:339-388).  The init list of such a context also clears DETAILED_DENSITIES_INERTIA_IMG (:142). */
 int fluid_run_step(fluid_ctx* ctx);
 
 /* Fence: wait until everything enqueued so far has executed (replaces fence wait main.cpp:124). */
@@ -412,6 +420,8 @@ typedef enum fluid_option {
                                    /* (default); 1 = process every cell                             */
     FLUID_OPT_ADVECT_KERNEL = 4,   /* 07_advect: 0 = velocity sampler tiled into LDS (default), 1 = taps    */
                                    /* straight from global memory                                    */
+    FLUID_OPT_SURFACE_KERNEL = 5,  /* 18_diffuse_float_densities: 0 = z-marching kernel (default), 1 = four */
+                                   /* cells per thread, one plane per workgroup                         */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

@@ -83,9 +83,13 @@ class SimulationDescriptors {
 public:
     SimulationDescriptors(const SimulationParametersBufferData& fluid_params_uniform_buffer,
                           uint64_t particle_space_size, uint32_t divergence_solve_iterations = 200,
-                          int device = -1) {
+                          int device = -1, bool surface_prep = false,
+                          uint32_t float_density_diffuse_steps = 4) {
         fluid_create_info info{};
         info.struct_bytes = sizeof info;
+        // the detailed-grid images of sections 15-18 (:58-63): 16 B x detailed_resolution^3 per cell
+        info.surface_prep = surface_prep ? 1u : 0u;
+        info.surface_diffuse_steps = float_density_diffuse_steps;
         info.device = device;
         info.params_blob = fluid_params_uniform_buffer.data();
         info.particle_capacity = particle_space_size;
@@ -164,7 +168,9 @@ inline int sectionIdFromShaderDir(const std::string& dir) {
         "03_update_air", "04_compute_extrapolated_velocities", "05_set_extrapolated_velocities",
         "06_update_cell_types", "07_advect", "08_forces", "09_diffuse", "10_solids",
         "11_compute_divergence", nullptr, nullptr, "12_solve_pressure", "13_fix_divergence",
-        "14_particles"};
+        "14_particles", nullptr, "15_update_detailed_densities",
+        "16_compute_detailed_densities_inertia", "17_compute_float_densities",
+        "18_diffuse_float_densities", nullptr};
     for (int i = 0; i < FLUID_SECTION_COUNT; i++)
         if (names[i] && dir == names[i]) return i;
     throw FluidError(FLUID_ERR_INVALID_ARG,
@@ -194,9 +200,12 @@ class FlowComputePushConstantSection : public FlowComputeSection {
 public:
     using FlowComputeSection::FlowComputeSection;
     void run(FlowDescriptorContext& ctx, uint32_t is_even_iteration) {
-        if (m_section != FLUID_SEC_12_SOLVE_PRESSURE)
+        if (m_section == FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES)
+            ctx.check(fluid_run_surface_diffuse_dispatch(ctx.handle(), is_even_iteration));
+        else if (m_section == FLUID_SEC_12_SOLVE_PRESSURE)
+            ctx.check(fluid_run_pressure_dispatch(ctx.handle(), is_even_iteration));
+        else
             throw FluidError(FLUID_ERR_INVALID_ARG, m_name + " takes no push constant");
-        ctx.check(fluid_run_pressure_dispatch(ctx.handle(), is_even_iteration));
     }
     using FlowComputeSection::run;
     int section() const { return m_section; }
@@ -273,13 +282,19 @@ private:
 // fluid_flow_sections.h:136-156 (minus the inertia clear :142, surface path)
 class SimulationInitializationSections : public FlowSectionList {
 public:
-    explicit SimulationInitializationSections(FlowDescriptorContext& flow_context)
-        : FlowSectionList{flow_context,
-                          {new FlowClearColorSection(flow_context, VELOCITIES_1,
-                                                     ClearValue(0.f, 0.f, 0.f, 0.f)),
-                           new FlowClearColorSection(flow_context, CELL_TYPES,
-                                                     ClearValue((uint32_t)CellType::CELL_INACTIVE)),
-                           new FlowComputeSection(flow_context, "00_init_particles")}} {}
+    // surface_prep: the context holds the detailed-grid images; the list then has the reference's
+    // inertia clear (:142) as well
+    explicit SimulationInitializationSections(FlowDescriptorContext& flow_context,
+                                              bool surface_prep = false)
+        : FlowSectionList{flow_context} {
+        add(new FlowClearColorSection(flow_context, VELOCITIES_1, ClearValue(0.f, 0.f, 0.f, 0.f)));
+        add(new FlowClearColorSection(flow_context, CELL_TYPES,
+                                      ClearValue((uint32_t)CellType::CELL_INACTIVE)));
+        if (surface_prep)
+            add(new FlowClearColorSection(flow_context, DETAILED_DENSITIES_INERTIA_IMG,
+                                          ClearValue((uint32_t)0)));
+        add(new FlowComputeSection(flow_context, "00_init_particles"));
+    }
 };
 
 // fluid_flow_sections.h:159-338 (01a … 14; 15-18 are the surface path)
@@ -311,6 +326,18 @@ public:
                    divergence_solve_iterations, flow_context, "12_solve_pressure"),
                new FlowComputeSection(flow_context, "13_fix_divergence"),
                new FlowComputeSection(flow_context, "14_particles")}} {}
+
+    // fluid_flow_sections.h:339-388: the surface-prep tail of the list (contexts created with
+    // surface_prep); call before complete()
+    void addSurfacePrepSections(FlowDescriptorContext& flow_context,
+                                uint32_t float_density_diffuse_steps = 4) {
+        add(new FlowClearColorSection(flow_context, DETAILED_DENSITIES_IMG, ClearValue((uint32_t)0)));
+        add(new FlowComputeSection(flow_context, "15_update_detailed_densities"));
+        add(new FlowComputeSection(flow_context, "16_compute_detailed_densities_inertia"));
+        add(new FlowComputeSection(flow_context, "17_compute_float_densities"));
+        add(new FlowLoopPushConstantSection<FlowComputePushConstantSection>(
+            float_density_diffuse_steps, flow_context, "18_diffuse_float_densities"));
+    }
 };
 
 }  // namespace fluid_amd

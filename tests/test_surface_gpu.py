@@ -62,7 +62,8 @@ def test_surface_section_matches_oracle(section, size, res):
         assert_state_equal(eng, st, ctx="the simulation images are untouched: ")
 
 
-def test_surface_loop_and_inertia_parameters():
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_surface_loop_and_inertia_parameters(kernel):
     st = surface_state((10, 8, 6), 4, seed=2)
     st.params.required_neighbour_hits = 2
     st.params.inertia_increase_neighbour = 3
@@ -70,12 +71,22 @@ def test_surface_loop_and_inertia_parameters():
     st.params.max_inertia = 90
     st.params.dens_diffuse_k = 0.13
     with engine_for(st) as eng:
+        eng.set_option(E.OPT_SURFACE_KERNEL, kernel)
         for s in ("16_compute_detailed_densities_inertia", "17_compute_float_densities"):
             eng.run_section(s)
             st.run_section(s)
         eng.run_section_loop("18_diffuse_float_densities", 5)
         st.diffuse_float_densities(5)
         assert_surface_equal(eng, st, "loop x5: ")
+
+
+def test_surface_diffuse_many_planes_and_partial_tiles():
+    """18 with the z-marching kernel over several z chunks (zchunk 32) and partial x / y tiles."""
+    st = surface_state((68, 5, 18), 4, seed=9, cap=100)   # detailed 272 x 20 x 72
+    with engine_for(st) as eng:
+        eng.run_section_loop("18_diffuse_float_densities", 3)
+        st.diffuse_float_densities(3)
+        assert_surface_equal(eng, st, "z march: ")
 
 
 def test_full_step_with_surface_prep_matches_oracle():
@@ -114,3 +125,27 @@ def test_surface_images_need_a_surface_context():
         assert ei.value.code == E.ERR_UNSUPPORTED
     with pytest.raises(fluid_amd.FluidEngineError):   # not on a Z slab
         fluid_amd.FluidEngine(p, particle_capacity=cap, slab=(0, 8), surface_prep=True)
+
+
+def test_cpp_section_lists_with_surface_prep(tmp_path):
+    """host/fluid_sim with `surface`: the C++ mirror's complete lists (init incl. the inertia clear, step
+    incl. 15-18 through FlowSectionList) against the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "vulkan-3d-fluid-simulation_amd", "host", "fluid_sim")
+    subprocess.run(["make", "-C", os.path.dirname(exe)], check=True, capture_output=True)
+    size, frames, iters = (16, 16, 16), 3, 6
+    res = subprocess.run([exe, *map(str, size), str(frames), str(iters), str(tmp_path), "surface"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "22 sections" in res.stdout  # 01a...14 plus the clear, 15, 16, 17 and the 18 loop
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters, surface_prep=True)
+    st.run_init()
+    for _ in range(frames):
+        st.run_step()
+    got = np.fromfile(os.path.join(str(tmp_path), "float_densities_1.bin"), dtype=np.float32)
+    assert_bit_equal(got.reshape(st.detailed_shape), st.float_densities_1, "C++ float densities")
+    got = np.fromfile(os.path.join(str(tmp_path), "particles.bin"), dtype=np.float32)
+    assert_bit_equal(got.reshape(st.particles.shape), st.particles, "C++ particles")

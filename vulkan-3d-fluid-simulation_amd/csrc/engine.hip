@@ -88,6 +88,7 @@ struct fluid_ctx {
     uint64_t surf_offset[4] = {0, 0, 0, 0};
     uint32_t surface_steps = 4;
     uint32_t surface_dispatch_index = 0;  // loop counter of the 18_diffuse_float_densities section
+    bool surface_fuse17 = false;          // inside fluid_run_step: 16 also writes what 17 would
     template <typename T>
     T* surf(int image_id) const {
         return reinterpret_cast<T*>(arena + surf_offset[image_id - 8]);
@@ -888,6 +889,7 @@ int run_section_impl(fluid_ctx* c, int section) {
                                "fluid_create_info.surface_prep", section);
             const SurfK& s = c->sk;
             const dim3 sgrid((s.W + 63) / 64, (s.H + 3) / 4, s.D);
+            const dim3 sgrid4((s.W / 4 + 63) / 64, (s.H + 3) / 4, s.D);  // four cells per thread
             uint32_t* det = c->surf<uint32_t>(FLUID_IMG_DETAILED_DENSITIES_IMG);
             uint32_t* inertia = c->surf<uint32_t>(FLUID_IMG_DETAILED_DENSITIES_INERTIA_IMG);
             float* f1 = c->surf<float>(FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1);
@@ -908,8 +910,14 @@ int run_section_impl(fluid_ctx* c, int section) {
                 k.decrease = (uint32_t)c->params.inertia_decrease;
                 k.required_hits = c->params.required_neighbour_hits;
                 k.increase_neighbour_i = c->params.inertia_increase_neighbour;
-                hipLaunchKernelGGL(k16_detailed_densities_inertia, sgrid, block, 0, c->stream, det,
-                                   inertia, s, k);
+                if (s.W % 4 == 0)  // fuse17: fluid_run_step writes FLOAT_1 from the same pass
+                    hipLaunchKernelGGL(k16_detailed_densities_inertia_v4, sgrid4, block, 0, c->stream,
+                                       det, inertia, c->surface_fuse17 ? f1 : (float*)nullptr, s, k,
+                                       c->params.dens_division_coefficient);
+                else
+                    hipLaunchKernelGGL(k16_detailed_densities_inertia, sgrid, block, 0, c->stream, det,
+                                       inertia, s, k);
+                if (c->surface_fuse17 && s.W % 4 == 0) c->surface_dispatch_index = 0;
             } else if (section == FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES) {
                 c->surface_dispatch_index = 0;
                 hipLaunchKernelGGL(k17_float_densities, sgrid, block, 0, c->stream, inertia, f1, s,
@@ -917,8 +925,21 @@ int run_section_impl(fluid_ctx* c, int section) {
             } else {  // one dispatch of the 18 loop; even dispatches read FLOAT_1 and write FLOAT_2
                 const bool even = (c->surface_dispatch_index % 2u) == 0u;
                 c->surface_dispatch_index++;
-                hipLaunchKernelGGL(k18_diffuse_float_densities, sgrid, block, 0, c->stream, T,
-                                   even ? f1 : f2, even ? f2 : f1, s, c->params.dens_diffuse_k, pk.t_solid);
+                if (s.W % 4 == 0 && c->opt[FLUID_OPT_SURFACE_KERNEL] == 0) {
+                    const int zchunk = 32;  // planes per workgroup: 2 extra plane loads per 32
+                    hipLaunchKernelGGL(k18_diffuse_float_densities_zmarch,
+                                       dim3((s.W / 4 + 63) / 64, (s.H + K18_ROWS - 1) / K18_ROWS,
+                                            (s.D + zchunk - 1) / zchunk),
+                                       dim3(64, K18_ROWS, 1), 0, c->stream, T, even ? f1 : f2,
+                                       even ? f2 : f1, s, c->params.dens_diffuse_k, pk.t_solid, zchunk);
+                } else if (s.W % 4 == 0)
+                    hipLaunchKernelGGL(k18_diffuse_float_densities_v4, sgrid4, block, 0, c->stream, T,
+                                       even ? f1 : f2, even ? f2 : f1, s, c->params.dens_diffuse_k,
+                                       pk.t_solid);
+                else
+                    hipLaunchKernelGGL(k18_diffuse_float_densities, sgrid, block, 0, c->stream, T,
+                                       even ? f1 : f2, even ? f2 : f1, s, c->params.dens_diffuse_k,
+                                       pk.t_solid);
             }
             break;
         }
@@ -1365,6 +1386,14 @@ int fluid_run_pressure_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {
     return rc ? rc : rc2;
 }
 
+int fluid_run_surface_diffuse_dispatch(fluid_ctx* c, uint32_t is_even_iteration) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the section's own counter decides the direction: set it so that this dispatch has the asked parity
+    c->surface_dispatch_index = is_even_iteration == 1u ? 0u : 1u;
+    return timed_section(c, FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES);
+}
+
 // ---- the loop section in explicit form (multi-GPU: the caller exchanges halos between launches) ----
 int fluid_pressure_loop_begin(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
@@ -1533,8 +1562,14 @@ static int run_surface_prep(fluid_ctx* c) {
                                 FLUID_SEC_15_UPDATE_DETAILED_DENSITIES,
                                 FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA,
                                 FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES};
+    // 17 is a pointwise function of the inertia 16 stores: one pass writes both images (four-cells-per-
+    // thread kernel, detailed width % 4 == 0) unless the section list is asked for
+    const bool fuse17 = c->opt[FLUID_OPT_STEP_FUSION] == 0 && c->sk.W % 4 == 0;
     for (int s : order) {
+        if (fuse17 && s == FLUID_SEC_17_COMPUTE_FLOAT_DENSITIES) continue;
+        c->surface_fuse17 = fuse17 && s == FLUID_SEC_16_COMPUTE_DETAILED_DENSITIES_INERTIA;
         int rc = timed_section(c, s);
+        c->surface_fuse17 = false;
         if (rc) return rc;
     }
     return fluid_run_section_loop(c, FLUID_SEC_18_DIFFUSE_FLOAT_DENSITIES, c->surface_steps);

@@ -121,4 +121,188 @@ __global__ void k18_diffuse_float_densities(const uint8_t* __restrict__ types,
     dst[id] = t1 + t2;
 }
 
+// ---- four cells per thread (detailed width % 4 == 0): 16-byte accesses along x, the y / z neighbours as
+// whole float4 / uint4 rows from L1 / L2, the two x neighbours outside the quad as scalars ---------------
+#define FLUID_SURF4_THREAD()                                    \
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);  \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;        \
+    const int z = blockIdx.z;                                   \
+    if (x >= s.W || y >= s.H) return;                           \
+    const int64_t id = sidx(s, x, y, z);
+
+// 16 (+ 17 when f1 != nullptr: the float image is a pointwise function of the inertia just computed)
+__global__ void k16_detailed_densities_inertia_v4(const uint32_t* __restrict__ detailed,
+                                                  uint32_t* __restrict__ inertia,
+                                                  float* __restrict__ f1, SurfK s, InertiaK k,
+                                                  float coefficient) {
+    FLUID_SURF4_THREAD();
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    auto row = [&](int ny, int nz) {
+        return ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
+                   ? *reinterpret_cast<const uint4*>(detailed + sidx(s, x, ny, nz))
+                   : zero;
+    };
+    const uint4 c = *reinterpret_cast<const uint4*>(detailed + id);
+    const uint4 yp = row(y + 1, z), ym = row(y - 1, z), zp = row(y, z + 1), zm = row(y, z - 1);
+    const uint32_t xl = x > 0 ? detailed[id - 1] : 0u, xr = x + 4 < s.W ? detailed[id + 4] : 0u;
+    const uint4 old = *reinterpret_cast<const uint4*>(inertia + id);
+    const uint32_t cc[4] = {c.x, c.y, c.z, c.w}, oo[4] = {old.x, old.y, old.z, old.w};
+    const uint32_t a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
+    const uint32_t a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
+    uint32_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t in = oo[i];
+        if (cc[i] > 0u) in += k.increase_filled;
+        const uint32_t nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
+        const uint32_t nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
+        int hits = 0;
+        hits += nxp > 0u ? 1 : 0;
+        hits += a_yp[i] > 0u ? 1 : 0;
+        hits += a_zp[i] > 0u ? 1 : 0;
+        hits += nxm > 0u ? 1 : 0;
+        hits += a_ym[i] > 0u ? 1 : 0;
+        hits += a_zm[i] > 0u ? 1 : 0;
+        if (hits >= k.required_hits) in += (uint32_t)(hits * k.increase_neighbour_i);
+        if (in == oo[i]) {
+            if (in > k.decrease)
+                in -= k.decrease;
+            else
+                in = 0u;
+        }
+        out[i] = min(k.max_inertia, in);
+    }
+    *reinterpret_cast<uint4*>(inertia + id) = make_uint4(out[0], out[1], out[2], out[3]);
+    if (f1) {  // 17_compute_float_densities on the values just stored
+        float4 f;
+        f.x = out[0] == 0u ? -1.0f : (float)out[0] / coefficient;
+        f.y = out[1] == 0u ? -1.0f : (float)out[1] / coefficient;
+        f.z = out[2] == 0u ? -1.0f : (float)out[2] / coefficient;
+        f.w = out[3] == 0u ? -1.0f : (float)out[3] / coefficient;
+        *reinterpret_cast<float4*>(f1 + id) = f;
+    }
+}
+
+__global__ void k18_diffuse_float_densities_v4(const uint8_t* __restrict__ types,
+                                               const float* __restrict__ src, float* __restrict__ dst,
+                                               SurfK s, float a, uint32_t t_solid) {
+    FLUID_SURF4_THREAD();
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto row = [&](int ny, int nz) {
+        return ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
+                   ? *reinterpret_cast<const float4*>(src + sidx(s, x, ny, nz))
+                   : zero;
+    };
+    const float4 c = *reinterpret_cast<const float4*>(src + id);
+    const float4 yp = row(y + 1, z), ym = row(y - 1, z), zp = row(y, z + 1), zm = row(y, z - 1);
+    const float xl = x > 0 ? src[id - 1] : 0.0f, xr = x + 4 < s.W ? src[id + 4] : 0.0f;
+    const float cc[4] = {c.x, c.y, c.z, c.w};
+    const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
+    const float a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
+    const int cy = y / s.res, cz = z / s.res;
+    const int64_t trow = (int64_t)s.sW * ((int64_t)cy + (int64_t)s.sH * (int64_t)cz);
+    const float k0 = 1.0f - 6.0f * a;
+    bool solid[4];
+    bool any_solid = false;
+    int cx = x / s.res, rem = x - cx * s.res;  // one division per thread: (x + i) / res by carrying
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        solid[i] = (uint32_t)types[trow + cx] == t_solid;
+        any_solid = any_solid || solid[i];
+        if (++rem == s.res) {
+            rem = 0;
+            cx++;
+        }
+    }
+    // cells of SOLID simulation cells are not written: they keep what the destination holds
+    float4 old = zero;
+    if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
+    float out[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (solid[i]) continue;
+        const float nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
+        const float nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
+        float sum = nxp + nxm;
+        sum = sum + a_yp[i];
+        sum = sum + a_ym[i];
+        sum = sum + a_zp[i];
+        sum = sum + a_zm[i];
+        const float t1 = k0 * cc[i];
+        const float t2 = a * sum;
+        out[i] = t1 + t2;
+    }
+    *reinterpret_cast<float4*>(dst + id) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// 18 with a z march: a workgroup of 64 x 8 threads owns 256 x 8 cells of an XY tile and walks `zchunk`
+// planes, every thread keeping the z-1 / z / z+1 values of its four cells in registers, so each texel of
+// the source leaves HBM once per dispatch (plus the tile's y halo rows and two planes per chunk) instead of
+// once per XCD that needs it as a z neighbour.  y neighbours are the rows of the adjacent threads of the
+// same workgroup (L1 hits) or the halo rows.  Same arithmetic as k18_diffuse_float_densities.
+constexpr int K18_ROWS = 8;
+__global__ void __launch_bounds__(64 * K18_ROWS)
+k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const float* __restrict__ src,
+                                   float* __restrict__ dst, SurfK s, float a, uint32_t t_solid,
+                                   int zchunk) {
+    const int x = 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int y = blockIdx.y * K18_ROWS + threadIdx.y;
+    if (x >= s.W || y >= s.H) return;  // no barriers in this kernel
+    const int zb = blockIdx.z * zchunk, ze = min(zb + zchunk, s.D);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float k0 = 1.0f - 6.0f * a;
+    const int64_t rowoff = (int64_t)x + (int64_t)s.W * (int64_t)y;
+    auto plane_ld = [&](int z) {
+        return (unsigned)z < (unsigned)s.D ? *reinterpret_cast<const float4*>(src + rowoff + s.plane * z)
+                                           : zero;
+    };
+    // this thread's simulation-cell columns (x is a multiple of 4; (x + i) / res by carrying)
+    const int cx0 = x / s.res, rem0 = x - cx0 * s.res, cy = y / s.res;
+    float4 zm = plane_ld(zb - 1), c = plane_ld(zb), zp = plane_ld(zb + 1);
+    for (int z = zb; z < ze; z++) {
+        const float4 zp2 = plane_ld(z + 2);  // two planes ahead: more bytes in flight per wavefront
+        const int64_t id = rowoff + s.plane * z;
+        const float4 yp = y + 1 < s.H ? *reinterpret_cast<const float4*>(src + id + s.W) : zero;
+        const float4 ym = y > 0 ? *reinterpret_cast<const float4*>(src + id - s.W) : zero;
+        const float xl = x > 0 ? src[id - 1] : 0.0f, xr = x + 4 < s.W ? src[id + 4] : 0.0f;
+        const int64_t trow = (int64_t)s.sW * ((int64_t)cy + (int64_t)s.sH * (int64_t)(z / s.res));
+        bool solid[4];
+        bool any_solid = false;
+        int cx = cx0, rem = rem0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            solid[i] = (uint32_t)types[trow + cx] == t_solid;
+            any_solid = any_solid || solid[i];
+            if (++rem == s.res) {
+                rem = 0;
+                cx++;
+            }
+        }
+        float4 old = zero;
+        if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
+        const float cc[4] = {c.x, c.y, c.z, c.w};
+        const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
+        const float a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
+        float out[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (solid[i]) continue;
+            const float nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
+            const float nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
+            float sum = nxp + nxm;
+            sum = sum + a_yp[i];
+            sum = sum + a_ym[i];
+            sum = sum + a_zp[i];
+            sum = sum + a_zm[i];
+            const float t1 = k0 * cc[i];
+            const float t2 = a * sum;
+            out[i] = t1 + t2;
+        }
+        *reinterpret_cast<float4*>(dst + id) = make_float4(out[0], out[1], out[2], out[3]);
+        zm = c;
+        c = zp;
+        zp = zp2;
+    }
+}
+
 }  // namespace fluid

@@ -59,6 +59,7 @@ OPT_JACOBI_FUSE = 1
 OPT_STEP_FUSION = 2
 OPT_QUIET_BRICKS = 3
 OPT_ADVECT_KERNEL = 4
+OPT_SURFACE_KERNEL = 5
 STAT_BRICKS, STAT_QUIET_BRICKS = 0, 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
@@ -71,6 +72,7 @@ EXPORTED_SYMBOLS = [
     "fluid_upload_buffer", "fluid_download_buffer", "fluid_image_bytes", "fluid_buffer_bytes",
     "fluid_set_params", "fluid_set_pressure_iterations", "fluid_set_diffuse_mode",
     "fluid_run_section", "fluid_run_section_loop", "fluid_run_section_group", "fluid_clear_image",
+    "fluid_run_surface_diffuse_dispatch",
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
@@ -141,6 +143,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_run_section": (C.c_int, [vp, C.c_int]),
         "fluid_run_section_loop": (C.c_int, [vp, C.c_int, u32]),
         "fluid_run_section_group": (C.c_int, [vp, C.c_int, u32]),
+        "fluid_run_surface_diffuse_dispatch": (C.c_int, [vp, u32]),
         "fluid_clear_image": (C.c_int, [vp, C.c_int, C.POINTER(u32 * 4)]),
         "fluid_run_pressure_dispatch": (C.c_int, [vp, u32]),
         "fluid_run_init": (C.c_int, [vp]),
@@ -334,6 +337,9 @@ class FluidEngine:
         """`count` consecutive step sections as one unit (include/fluid_engine.h)."""
         sid = SECTION_IDS[first_section] if isinstance(first_section, str) else int(first_section)
         self._check(self._lib.fluid_run_section_group(self._h, sid, count))
+
+    def run_surface_diffuse_dispatch(self, is_even_iteration: int):
+        self._check(self._lib.fluid_run_surface_diffuse_dispatch(self._h, is_even_iteration))
 
     def solve_pressure(self, iterations: int):
         """The 12_solve_pressure loop section (fluid_flow_sections.h:300-313)."""

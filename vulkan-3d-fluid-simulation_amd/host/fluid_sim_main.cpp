@@ -2,7 +2,11 @@
 // (/root/reference/main.cpp:68-124 set-up + init submit, :156-177 per-frame step submit) on the
 // MI355X engine, through the C++ section-list mirror (include/fluid_flow_sections_amd.hpp).
 //
-//   fluid_sim <W> <H> <D> <frames> <jacobi_iters> [out_dir]
+//   fluid_sim <W> <H> <D> <frames> <jacobi_iters> [out_dir] [surface]
+//
+// With the word `surface` the lists are the reference's complete ones: the init list also clears the
+// inertia image and the step list ends with the surface-prep passes 15…18 on the detailed grid
+// (fluid_flow_sections.h:142, 339-388); the float density image is dumped as well.
 //
 // Uses the dam-break scene of the benchmark plan (reference spawn cube scaled to the grid,
 // 8 particles per cell).  Prints per-frame time and, when out_dir is given, dumps VELOCITIES_1,
@@ -33,6 +37,7 @@ int main(int argc, char** argv) {
     const int frames = std::atoi(argv[4]);
     const uint32_t divergence_solve_iterations = (uint32_t)std::atoi(argv[5]);
     const std::string out_dir = argc > 6 ? argv[6] : "";
+    const bool surface = argc > 7 && std::string(argv[7]) == "surface";
     try {
         // dam-break spawn cube: ratios of simulation_constants.h:48-50 to the 20^3 grid
         const float size[3] = {0.5f * fluid_size.x, 0.5f * fluid_size.y, 0.1f * fluid_size.z};
@@ -53,12 +58,14 @@ int main(int argc, char** argv) {
         }
         params.params().particle_spawn_cube_volume = particle_space_size;
         // main.cpp:73  all images and buffers
-        SimulationDescriptors descriptors(params, particle_space_size, divergence_solve_iterations);
+        SimulationDescriptors descriptors(params, particle_space_size, divergence_solve_iterations, -1,
+                                          surface);
         FlowDescriptorContext& flow_context = descriptors;
         // main.cpp:76,79  section lists; :103-104 complete()
-        SimulationInitializationSections init_sections(flow_context);
+        SimulationInitializationSections init_sections(flow_context, surface);
         SimulationStepSections draw_section_list(flow_context, divergence_solve_iterations,
                                                  params.params().pressure_air);
+        if (surface) draw_section_list.addSurfacePrepSections(flow_context);  // :339-388
         init_sections.complete();
         draw_section_list.complete();
         // main.cpp:111-124  run the init list and wait
@@ -80,6 +87,11 @@ int main(int argc, char** argv) {
                 std::vector<uint8_t> buf(descriptors.bytes(imgs[i]));
                 descriptors.download(imgs[i], buf.data(), buf.size());
                 dump(out_dir + "/" + names[i] + ".bin", buf);
+            }
+            if (surface) {
+                std::vector<uint8_t> buf(descriptors.bytes(PARTICLE_DENSITIES_FLOAT_1));
+                descriptors.download(PARTICLE_DENSITIES_FLOAT_1, buf.data(), buf.size());
+                dump(out_dir + "/float_densities_1.bin", buf);
             }
             std::vector<uint8_t> part((size_t)particle_space_size * 16);
             descriptors.download(PARTICLES_BUF, part.data(), part.size());
