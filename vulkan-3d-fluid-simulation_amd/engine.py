@@ -302,6 +302,39 @@ class FluidEngine:
         self._check(self._lib.fluid_download_image(self._h, image_id, out.ctypes.data, out.nbytes))
         return out
 
+    # -- state I/O: everything a step reads, as one .npz -------------------------
+    def save_checkpoint(self, path: str):
+        """Images 0..7 (and the detailed-grid images of a surface_prep context), the particle buffer and
+        the parameter block.  Whole-grid contexts; a Z-slab run gathers per image (slab.SlabSimulation)."""
+        data = {"params": np.frombuffer(self.params.to_bytes(), dtype=np.uint8),
+                "particles": self.download_particles(),
+                "meta": np.array([self.particle_capacity, 1 if self.surface_prep else 0], np.int64)}
+        for img in IMAGE_DTYPES:
+            data[f"image_{img}"] = self.download_image(img)
+        if self.surface_prep:
+            for img in SURFACE_DTYPES:
+                data[f"image_{img}"] = self.download_image(img)
+        np.savez(path, **data)
+
+    def restore_checkpoint(self, path: str):
+        """Load a checkpoint written by save_checkpoint into this context (same grid, capacity and
+        parameter block sizes; the parameter values of the file replace the context's)."""
+        with np.load(path, allow_pickle=False) as z:
+            blob = z["params"].tobytes()
+            if len(blob) != PARAMS_BYTES or int(z["meta"][0]) != self.particle_capacity:
+                raise FluidEngineError(ERR_SIZE_MISMATCH, "checkpoint does not fit this context")
+            params = FluidParams.from_buffer_copy(blob)
+            if tuple(params.size) != tuple(self.global_size):
+                raise FluidEngineError(ERR_SIZE_MISMATCH, "checkpoint grid differs from this context's")
+            self.set_params(params)
+            for img in IMAGE_DTYPES:
+                self.upload_image(img, z[f"image_{img}"])
+            if self.surface_prep and int(z["meta"][1]):
+                for img in SURFACE_DTYPES:
+                    self.upload_image(img, z[f"image_{img}"])
+            if self.particle_capacity:
+                self.upload_particles(z["particles"])
+
     def upload_particles(self, particles: np.ndarray):
         particles = np.ascontiguousarray(particles, dtype=np.float32)
         self._check(self._lib.fluid_upload_buffer(self._h, PARTICLES_BUF, particles.ctypes.data,
