@@ -236,69 +236,98 @@ __global__ void k18_diffuse_float_densities_v4(const uint8_t* __restrict__ types
 }
 
 // 18 with a z march: a workgroup of 64 x 8 threads owns 256 x 8 cells of an XY tile and walks `zchunk`
-// planes, every thread keeping the z-1 / z / z+1 values of its four cells in registers, so each texel of
-// the source leaves HBM once per dispatch (plus the tile's y halo rows and two planes per chunk) instead of
-// once per XCD that needs it as a z neighbour.  y neighbours are the rows of the adjacent threads of the
-// same workgroup (L1 hits) or the halo rows.  Same arithmetic as k18_diffuse_float_densities.
+// planes.  Every thread keeps the z-1 / z / z+1 values of its four cells in registers and publishes the
+// current plane's in LDS (double-buffered, one barrier per plane), where its neighbours find their y and x
+// neighbours; only the tile's two halo rows and two edge columns come from global memory.  Each texel of
+// the source then leaves HBM about 1.3 times per dispatch (PMC: the version that loaded the y neighbours
+// from global memory fetched 2.8 times — three planes of every resident workgroup do not stay in a 4-MiB
+// L2 next to the output stream).  Same arithmetic as k18_diffuse_float_densities.
 constexpr int K18_ROWS = 8;
+constexpr int K18_PAD = 4;                      // floats left of x = 0 of the tile (keeps rows 16-B aligned)
+constexpr int K18_ROW_FLOATS = 256 + 2 * K18_PAD;
 __global__ void __launch_bounds__(64 * K18_ROWS)
 k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const float* __restrict__ src,
                                    float* __restrict__ dst, SurfK s, float a, uint32_t t_solid,
                                    int zchunk) {
-    const int x = 4 * (blockIdx.x * 64 + threadIdx.x);
-    const int y = blockIdx.y * K18_ROWS + threadIdx.y;
-    if (x >= s.W || y >= s.H) return;  // no barriers in this kernel
+    __shared__ __attribute__((aligned(16))) float tile[2][K18_ROWS + 2][K18_ROW_FLOATS];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = 4 * (blockIdx.x * 64 + tx);
+    const int y = blockIdx.y * K18_ROWS + ty;
+    const bool valid = x < s.W && y < s.H;  // invalid threads still take part in the barriers
     const int zb = blockIdx.z * zchunk, ze = min(zb + zchunk, s.D);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const float k0 = 1.0f - 6.0f * a;
     const int64_t rowoff = (int64_t)x + (int64_t)s.W * (int64_t)y;
     auto plane_ld = [&](int z) {
-        return (unsigned)z < (unsigned)s.D ? *reinterpret_cast<const float4*>(src + rowoff + s.plane * z)
-                                           : zero;
+        return (valid && (unsigned)z < (unsigned)s.D)
+                   ? *reinterpret_cast<const float4*>(src + rowoff + s.plane * z)
+                   : zero;
     };
+    // halo rows of the tile: the first / last thread row also loads the row below / above the tile
+    const bool halo_row = ty == 0 || ty == K18_ROWS - 1;
+    const int yh = ty == 0 ? y - 1 : y + 1;
+    const bool halo_in = halo_row && x < s.W && (unsigned)yh < (unsigned)s.H;
+    const int64_t halo_off = (int64_t)x + (int64_t)s.W * (int64_t)(halo_in ? yh : 0);
+    // edge columns: lane 0 supplies x - 1, lane 63 supplies x + 4 of its row
+    const bool edge = tx == 0 || tx == 63;
+    const int xe = tx == 0 ? x - 1 : x + 4;
+    const bool edge_in = edge && valid && (unsigned)xe < (unsigned)s.W;
     // this thread's simulation-cell columns (x is a multiple of 4; (x + i) / res by carrying)
     const int cx0 = x / s.res, rem0 = x - cx0 * s.res, cy = y / s.res;
     float4 zm = plane_ld(zb - 1), c = plane_ld(zb), zp = plane_ld(zb + 1);
     for (int z = zb; z < ze; z++) {
+        const int buf = z & 1;
         const float4 zp2 = plane_ld(z + 2);  // two planes ahead: more bytes in flight per wavefront
         const int64_t id = rowoff + s.plane * z;
-        const float4 yp = y + 1 < s.H ? *reinterpret_cast<const float4*>(src + id + s.W) : zero;
-        const float4 ym = y > 0 ? *reinterpret_cast<const float4*>(src + id - s.W) : zero;
-        const float xl = x > 0 ? src[id - 1] : 0.0f, xr = x + 4 < s.W ? src[id + 4] : 0.0f;
-        const int64_t trow = (int64_t)s.sW * ((int64_t)cy + (int64_t)s.sH * (int64_t)(z / s.res));
-        bool solid[4];
-        bool any_solid = false;
-        int cx = cx0, rem = rem0;
+        // publish plane z of this tile
+        float* row = &tile[buf][ty + 1][K18_PAD + 4 * tx];
+        *reinterpret_cast<float4*>(row) = c;
+        if (halo_row) {
+            const float4 h = halo_in ? *reinterpret_cast<const float4*>(src + halo_off + s.plane * z) : zero;
+            *reinterpret_cast<float4*>(&tile[buf][ty == 0 ? 0 : K18_ROWS + 1][K18_PAD + 4 * tx]) = h;
+        }
+        if (edge) row[tx == 0 ? -1 : 4] = edge_in ? src[id + (tx == 0 ? -1 : 4)] : 0.0f;
+        __syncthreads();
+        if (valid) {
+            // rows outside the image hold 0 (the halo loads above / plane_ld of invalid rows)
+            const float4 yp = *reinterpret_cast<const float4*>(&tile[buf][ty + 2][K18_PAD + 4 * tx]);
+            const float4 ym = *reinterpret_cast<const float4*>(&tile[buf][ty][K18_PAD + 4 * tx]);
+            const float xl = row[-1], xr = row[4];
+            const int64_t trow = (int64_t)s.sW * ((int64_t)cy + (int64_t)s.sH * (int64_t)(z / s.res));
+            bool solid[4];
+            bool any_solid = false;
+            int cx = cx0, rem = rem0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            solid[i] = (uint32_t)types[trow + cx] == t_solid;
-            any_solid = any_solid || solid[i];
-            if (++rem == s.res) {
-                rem = 0;
-                cx++;
+            for (int i = 0; i < 4; i++) {
+                solid[i] = (uint32_t)types[trow + cx] == t_solid;
+                any_solid = any_solid || solid[i];
+                if (++rem == s.res) {
+                    rem = 0;
+                    cx++;
+                }
             }
-        }
-        float4 old = zero;
-        if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
-        const float cc[4] = {c.x, c.y, c.z, c.w};
-        const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
-        const float a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
-        float out[4] = {old.x, old.y, old.z, old.w};
+            float4 old = zero;
+            if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
+            const float cc[4] = {c.x, c.y, c.z, c.w};
+            const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
+            const float a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
+            float out[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (solid[i]) continue;
-            const float nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
-            const float nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
-            float sum = nxp + nxm;
-            sum = sum + a_yp[i];
-            sum = sum + a_ym[i];
-            sum = sum + a_zp[i];
-            sum = sum + a_zm[i];
-            const float t1 = k0 * cc[i];
-            const float t2 = a * sum;
-            out[i] = t1 + t2;
+            for (int i = 0; i < 4; i++) {
+                if (solid[i]) continue;
+                const float nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
+                const float nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
+                float sum = nxp + nxm;
+                sum = sum + a_yp[i];
+                sum = sum + a_ym[i];
+                sum = sum + a_zp[i];
+                sum = sum + a_zm[i];
+                const float t1 = k0 * cc[i];
+                const float t2 = a * sum;
+                out[i] = t1 + t2;
+            }
+            *reinterpret_cast<float4*>(dst + id) = make_float4(out[0], out[1], out[2], out[3]);
         }
-        *reinterpret_cast<float4*>(dst + id) = make_float4(out[0], out[1], out[2], out[3]);
         zm = c;
         c = zp;
         zp = zp2;
