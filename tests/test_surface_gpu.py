@@ -125,6 +125,11 @@ def test_surface_images_need_a_surface_context():
         assert ei.value.code == E.ERR_UNSUPPORTED
     with pytest.raises(fluid_amd.FluidEngineError):   # not on a Z slab
         fluid_amd.FluidEngine(p, particle_capacity=cap, slab=(0, 8), surface_prep=True)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, surface_prep=True) as eng:
+        q = p.copy()
+        q.detailed_resolution = 3   # the detailed images were sized for 5
+        with pytest.raises(fluid_amd.FluidEngineError, match="detailed_resolution"):
+            eng.set_params(q)
 
 
 def test_cpp_section_lists_with_surface_prep(tmp_path):

@@ -1281,6 +1281,10 @@ int fluid_set_params(fluid_ctx* c, const void* blob) {
     for (int i = 0; i < 3; i++)
         if (p.fluid_size[i] != c->params.fluid_size[i])
             return c->fail(FLUID_ERR_SIZE_MISMATCH, "fluid_size cannot change on a live context");
+    if (c->surface && p.detailed_resolution != c->sk.res)
+        return c->fail(FLUID_ERR_SIZE_MISMATCH,
+                       "detailed_resolution cannot change on a surface_prep context (the detailed "
+                       "images were allocated for %d)", c->sk.res);
     c->params = p;
     c->pk = make_params_k(p);
     c->params_changed();  // cell type values, rho, dx, dt, p_air may have changed
