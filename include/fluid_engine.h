@@ -402,6 +402,19 @@ int fluid_particles_adopt(fluid_ctx* ctx, const void* device_list, uint32_t coun
 int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* slab_z_begin,
                        uint32_t* slab_z_count, uint64_t* particle_capacity);
 
+/* ---- opt-in pressure solver — NOT the reference's algorithm or results ----------
+ * FLUID_SOLVER_JACOBI (default): 12_solve_pressure as the reference runs it.
+ * FLUID_SOLVER_RED_BLACK_SOR: the same linear system (pressure.comp:41-62) relaxed by red-black
+ * successive over-relaxation.  One iteration updates in place on PRESSURES_1 first the WATER cells with
+ * (x + y + z) even, then the odd ones: gs = -s / aii from the current image, P += omega * (gs - P).
+ * fluid_run_section(12) = one iteration; fluid_run_section_loop(12, n) (and fluid_run_step) = n
+ * iterations followed by PRESSURES_2 := PRESSURES_1, so that 13_fix_divergence uses the final iterate.
+ * For the same ERROR it needs a small fraction of the Jacobi iterations on pool-like scenes (the residual
+ * is not the yardstick: over-relaxation keeps it large while the error collapses).
+ * Whole-grid contexts only.  Results are bit-identical to the oracle's restatement of this solver. */
+typedef enum fluid_solver { FLUID_SOLVER_JACOBI = 0, FLUID_SOLVER_RED_BLACK_SOR = 1 } fluid_solver;
+int fluid_set_pressure_solver(fluid_ctx* ctx, int solver, float omega);
+
 /* ---- engine options (performance variants of the same arithmetic; results are bit-identical) -- */
 typedef enum fluid_option {
     FLUID_OPT_PRESSURE_KERNEL = 0, /* 0 = auto.  Single dispatches: 1 = one cell per thread, 2/3/4 =  */

@@ -436,6 +436,53 @@ void oracle_12_solve_pressure_loop(const fluid_params* p, const uint8_t* types, 
         oracle_12_solve_pressure(p, types, div, p1, p2, (k % 2u) == 0u ? 1u : 0u);
 }
 
+/* ---- opt-in pressure solver (NOT in the reference): red-black successive over-
+ * relaxation on the linear system of pressure.comp:41-62.  One iteration updates, in place, first the
+ * WATER cells with (x + y + z) even, then those with (x + y + z) odd:
+ *     gs = -s / aii   with s as in the Jacobi sweep but from the CURRENT contents of `pr`
+ *     pr = pr + omega * (gs - pr)
+ * Cells of one colour have no neighbour of the same colour, so the order inside a colour is immaterial. */
+void oracle_12_sor_iteration(const fluid_params* p, const uint8_t* types, const float* div, float* pr,
+                             float omega) {
+    grid g = grid_of(p);
+    const uint32_t water = p->cell_type_water, solid = p->cell_type_solid;
+    static const int mv[6][3] = {{1, 0, 0},  {0, 1, 0},  {0, 0, 1},
+                                 {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
+    for (int colour = 0; colour < 2; colour++)
+        for (int z = 0; z < g.D; z++)
+            for (int y = 0; y < g.H; y++)
+                for (int x = 0; x < g.W; x++) {
+                    if (((x + y + z) & 1) != colour) continue;
+                    uint64_t id = cell(g, x, y, z);
+                    if (types[id] != water) continue;
+                    int aii = 0;
+                    float s = ((div[id] * p->fluid_density) * p->cell_width) / p->time_delta;
+                    for (int j = 0; j < 6; j++) {
+                        int nx = x + mv[j][0], ny = y + mv[j][1], nz = z + mv[j][2];
+                        uint32_t t = type_at(g, types, nx, ny, nz);
+                        if (t != solid) {
+                            if (t == water)
+                                s = s - f32_at(g, pr, nx, ny, nz);
+                            else
+                                s = s - p->pressure_air;
+                            aii++;
+                        }
+                    }
+                    const float gs = -s / (float)aii;
+                    const float d = gs - pr[id];
+                    const float t2 = omega * d;
+                    pr[id] = pr[id] + t2;
+                }
+}
+/* the loop section under this solver: `iterations` iterations on PRESSURES_1, then PRESSURES_2 :=
+ * PRESSURES_1 (13_fix_divergence reads PRESSURES_2) */
+void oracle_12_sor_loop(const fluid_params* p, const uint8_t* types, const float* div, float* p1,
+                        float* p2, float omega, uint32_t iterations) {
+    grid g = grid_of(p);
+    for (uint32_t k = 0; k < iterations; k++) oracle_12_sor_iteration(p, types, div, p1, omega);
+    memcpy(p2, p1, sizeof(float) * (size_t)g.W * g.H * g.D);
+}
+
 /* ---- 13_fix_divergence/fix_divergence.comp:41-72 -------------------------------------------------- */
 void oracle_13_fix_divergence(const fluid_params* p, const uint8_t* types, const float* pr,
                               float* v1) {

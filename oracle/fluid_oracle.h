@@ -60,6 +60,11 @@ void oracle_12_solve_pressure(const fluid_params* p, const uint8_t* types, const
 /* the loop section: `iterations` dispatches, dispatch k has is_even_iteration = (k%2==0) */
 void oracle_12_solve_pressure_loop(const fluid_params* p, const uint8_t* types, const float* div,
                                    float* p1, float* p2, uint32_t iterations);
+/* opt-in red-black SOR on the same system (not in the reference; fluid_oracle.c) */
+void oracle_12_sor_iteration(const fluid_params* p, const uint8_t* types, const float* div, float* pr,
+                             float omega);
+void oracle_12_sor_loop(const fluid_params* p, const uint8_t* types, const float* div, float* p1,
+                        float* p2, float omega, uint32_t iterations);
 void oracle_13_fix_divergence(const fluid_params* p, const uint8_t* types, const float* p2,
                               float* v1);
 void oracle_14_particles(const fluid_params* p, const float* v1, float* particles,

@@ -62,6 +62,8 @@ def lib():
         "oracle_12_solve_pressure_loop": [pp, vp, vp, vp, vp, u32],
         "oracle_13_fix_divergence": [pp, vp, vp, vp],
         "oracle_14_particles": [pp, vp, vp, u64],
+        "oracle_12_sor_iteration": [pp, vp, vp, vp, C.c_float],
+        "oracle_12_sor_loop": [pp, vp, vp, vp, vp, C.c_float, u32],
         "oracle_15_update_detailed_densities": [pp, vp, u64, vp],
         "oracle_16_compute_detailed_densities_inertia": [pp, vp, vp],
         "oracle_17_compute_float_densities": [pp, vp, vp],
@@ -126,6 +128,7 @@ class OracleState:
                         self.surface_prep, self.surface_diffuse_steps)
         for f in self.FIELDS + (self.SURFACE_FIELDS if self.surface_prep else []):
             getattr(o, f)[...] = getattr(self, f)
+        o.sor_omega = self.sor_omega
         return o
 
     # ---- sections (names = engine section names) ------------------------------------------------
@@ -218,7 +221,14 @@ class OracleState:
                                        _ptr(self.pressures_1), _ptr(self.pressures_2),
                                        is_even_iteration)
 
+    sor_omega = None   # set to a float: the opt-in red-black SOR solver replaces the Jacobi loop
+
     def solve_pressure(self, iterations: int):
+        if self.sor_omega is not None:
+            lib().oracle_12_sor_loop(self._p, _ptr(self.cell_types), _ptr(self.divergences),
+                                     _ptr(self.pressures_1), _ptr(self.pressures_2),
+                                     float(self.sor_omega), iterations)
+            return
         lib().oracle_12_solve_pressure_loop(self._p, _ptr(self.cell_types),
                                             _ptr(self.divergences), _ptr(self.pressures_1),
                                             _ptr(self.pressures_2), iterations)

@@ -76,6 +76,8 @@ struct fluid_ctx {
     uint32_t pressure_iterations = 200;
     int diffuse_mode = FLUID_DIFFUSE_REFERENCE_EXACT;
     uint32_t pressure_dispatch_index = 0;  // loop counter of the 12_solve_pressure section
+    int solver = FLUID_SOLVER_JACOBI;      // opt-in: FLUID_SOLVER_RED_BLACK_SOR (not the reference's results)
+    float sor_omega = 1.0f;
     bool is_slab = false;
 
     ImageDesc img[8];
@@ -866,6 +868,15 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         }
         case FLUID_SEC_12_SOLVE_PRESSURE: {
+            if (c->solver == FLUID_SOLVER_RED_BLACK_SOR) {  // one iteration, in place on PRESSURES_1
+                if (c->is_slab) return slab_unsupported(c, "the red-black SOR solver");
+                float* p1 = c->plane0<float>(FLUID_IMG_PRESSURES_1);
+                for (int colour = 0; colour < 2; colour++)
+                    k12_launch_sor_colour(c->stream, T, c->plane0<float>(FLUID_IMG_DIVERGENCES), p1, g,
+                                          pk, c->sor_omega, colour);
+                c->pressure_dispatch_index++;
+                break;
+            }
             const uint32_t even = (c->pressure_dispatch_index % 2u) == 0u ? 1u : 0u;
             c->pressure_dispatch_index++;
             return launch_pressure(c, even);
@@ -1350,6 +1361,19 @@ int fluid_set_diffuse_mode(fluid_ctx* c, int mode) {
     return FLUID_OK;
 }
 
+int fluid_set_pressure_solver(fluid_ctx* c, int solver, float omega) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (solver != FLUID_SOLVER_JACOBI && solver != FLUID_SOLVER_RED_BLACK_SOR)
+        return c->fail(FLUID_ERR_INVALID_ARG, "unknown solver %d", solver);
+    if (solver == FLUID_SOLVER_RED_BLACK_SOR && !(omega > 0.0f && omega < 2.0f))
+        return c->fail(FLUID_ERR_INVALID_ARG, "SOR needs 0 < omega < 2, got %g", (double)omega);
+    if (solver == FLUID_SOLVER_RED_BLACK_SOR && c->is_slab)
+        return slab_unsupported(c, "the red-black SOR solver");
+    c->solver = solver;
+    c->sor_omega = omega;
+    return FLUID_OK;
+}
+
 int fluid_set_option(fluid_ctx* c, int option, int64_t value) {
     if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
@@ -1527,6 +1551,20 @@ int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
     HIP_TRY(c, hipSetDevice(c->device));
     // FlowLoopPushConstantSection (fluid_flow_sections.h:300-313): the loop owns its own counter —
     // dispatch k of this call has is_even_iteration = (k % 2 == 0).
+    if (c->solver == FLUID_SOLVER_RED_BLACK_SOR) {
+        // opt-in: `iterations` red-black SOR iterations on PRESSURES_1, then PRESSURES_2 := PRESSURES_1
+        // (13_fix_divergence reads PRESSURES_2)
+        if (c->is_slab) return slab_unsupported(c, "the red-black SOR solver");
+        c->pressure_dispatch_index = 0;
+        for (uint32_t k = 0; k < iterations; k++) {
+            int rc = timed_section(c, FLUID_SEC_12_SOLVE_PRESSURE);
+            if (rc) return rc;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->plane0<float>(FLUID_IMG_PRESSURES_2),
+                                  c->plane0<float>(FLUID_IMG_PRESSURES_1), c->owned_cells() * 4,
+                                  hipMemcpyDeviceToDevice, c->stream));
+        return FLUID_OK;
+    }
     SectionTimer tm{c};
     int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
     if (rc) return rc;

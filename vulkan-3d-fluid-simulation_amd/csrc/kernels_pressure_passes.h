@@ -219,4 +219,43 @@ k12_residual(const uint8_t* __restrict__ t, const float* __restrict__ div,
     }
 }
 
+// ---- opt-in pressure solver (not in the reference): one colour of a red-black SOR
+// iteration, in place on PRESSURES_1.  One thread per cell of the colour: x = 2 i + ((y + z + colour) & 1).
+//     gs = -s / aii (s as in the Jacobi sweep, from the current image);  P = P + omega * (gs - P)
+// Same-colour cells are not neighbours, so the update order inside a launch does not matter and the
+// result is bit-identical to the oracle's sequential loop (oracle_12_sor_iteration).
+__global__ void k12_sor_colour(const uint8_t* __restrict__ t, const float* __restrict__ div,
+                               float* __restrict__ pr, GridK g, ParamsK p, float omega, int colour) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int lz = blockIdx.z;
+    const int x = 2 * i + ((y + g.z0 + lz + colour) & 1);
+    if (x >= g.W || y >= g.H) return;
+    const int64_t id = cidx(g, x, y, lz);
+    if ((uint32_t)t[id] != p.t_water) return;
+    int aii = 0;
+    float s = ((div[id] * p.rho) * p.dx) / p.dt;
+    auto nb = [&](uint32_t ty, float q) {
+        if (ty != p.t_solid) {
+            s = s - (ty == p.t_water ? q : p.p_air);
+            aii++;
+        }
+    };
+    const uint32_t txp = type_at(t, g, x + 1, y, lz), typ = type_at(t, g, x, y + 1, lz);
+    const uint32_t tzp = t[cidx(g, x, y, lz + 1)];
+    const uint32_t txm = type_at(t, g, x - 1, y, lz), tym = type_at(t, g, x, y - 1, lz);
+    const uint32_t tzm = t[cidx(g, x, y, lz - 1)];
+    nb(txp, txp == p.t_water ? f32_at(pr, g, x + 1, y, lz) : 0.f);
+    nb(typ, typ == p.t_water ? f32_at(pr, g, x, y + 1, lz) : 0.f);
+    nb(tzp, tzp == p.t_water ? pr[cidx(g, x, y, lz + 1)] : 0.f);
+    nb(txm, txm == p.t_water ? f32_at(pr, g, x - 1, y, lz) : 0.f);
+    nb(tym, tym == p.t_water ? f32_at(pr, g, x, y - 1, lz) : 0.f);
+    nb(tzm, tzm == p.t_water ? pr[cidx(g, x, y, lz - 1)] : 0.f);
+    const float gs = -s / (float)aii;
+    const float old = pr[id];
+    const float d = gs - old;
+    const float t2 = omega * d;
+    pr[id] = old + t2;
+}
+
 }  // namespace fluid

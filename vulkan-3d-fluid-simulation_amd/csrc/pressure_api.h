@@ -43,6 +43,9 @@ void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, 
                           float* p1, float* p2, const GridK& g, const ParamsK& p);
 // out[0..6] = {bricks with water, y brick range lo, hi, z brick range lo, hi, x CELL range lo, hi (from
 // the mask pass's x_extent)}
+// one colour (0 / 1) of a red-black SOR iteration in place on a pressure image (opt-in solver)
+void k12_launch_sor_colour(hipStream_t s, const uint8_t* t, const float* div, float* pr, const GridK& g,
+                           const ParamsK& p, float omega, int colour);
 // convergence read-out: out32 = 32 zeroed bytes {uint32 max|r| bits, pad, double sum r^2, uint64 water cells}
 void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
                          const GridK& g, const ParamsK& p, void* out32);

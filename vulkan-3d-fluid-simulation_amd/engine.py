@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "fluid_upload_buffer", "fluid_download_buffer", "fluid_image_bytes", "fluid_buffer_bytes",
     "fluid_set_params", "fluid_set_pressure_iterations", "fluid_set_diffuse_mode",
     "fluid_run_section", "fluid_run_section_loop", "fluid_run_section_group", "fluid_clear_image",
-    "fluid_run_surface_diffuse_dispatch",
+    "fluid_run_surface_diffuse_dispatch", "fluid_set_pressure_solver",
     "fluid_run_pressure_dispatch", "fluid_run_init",
     "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
@@ -144,6 +144,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_run_section_loop": (C.c_int, [vp, C.c_int, u32]),
         "fluid_run_section_group": (C.c_int, [vp, C.c_int, u32]),
         "fluid_run_surface_diffuse_dispatch": (C.c_int, [vp, u32]),
+        "fluid_set_pressure_solver": (C.c_int, [vp, C.c_int, C.c_float]),
         "fluid_clear_image": (C.c_int, [vp, C.c_int, C.POINTER(u32 * 4)]),
         "fluid_run_pressure_dispatch": (C.c_int, [vp, u32]),
         "fluid_run_init": (C.c_int, [vp]),
@@ -370,6 +371,12 @@ class FluidEngine:
         """`count` consecutive step sections as one unit (include/fluid_engine.h)."""
         sid = SECTION_IDS[first_section] if isinstance(first_section, str) else int(first_section)
         self._check(self._lib.fluid_run_section_group(self._h, sid, count))
+
+    SOLVER_JACOBI, SOLVER_RED_BLACK_SOR = 0, 1
+
+    def set_pressure_solver(self, solver: int, omega: float = 1.0):
+        """Opt-in red-black SOR for the pressure system (include/fluid_engine.h; not the reference's)."""
+        self._check(self._lib.fluid_set_pressure_solver(self._h, solver, omega))
 
     def run_surface_diffuse_dispatch(self, is_even_iteration: int):
         self._check(self._lib.fluid_run_surface_diffuse_dispatch(self._h, is_even_iteration))
