@@ -380,6 +380,8 @@ int fluid_notify_ghost_planes_written(fluid_ctx* ctx, int image_id);
  *   after the pressure loop: PRESSURES_2, 1 plane           (13 reads z-1)
  *   after 13: VELOCITIES_1, FLUID_IMAGE_GHOST_PLANES planes (14 samples it)
  *   after 14: particle migration (below)
+ * In FLUID_DIFFUSE_INTENDED mode 09 is a 7-point stencil: VELOCITIES_2, 1 plane, after 08 (and the
+ * sections 09, 10, 11 one by one: the grouped 09+10+11 exists for the reference-exact copy only).
  * With the grouped passes (fluid_run_section_group): 04+05 in place of 04, 05; 07+08 in place of 07,
  * 08; and, instead of the one-plane VELOCITIES_1 exchange after 10, one plane of VELOCITIES_2 after 08
  * followed by 09+10+11.

@@ -99,6 +99,9 @@ class HostGlobalCompute:
             for f in WRITES[name]:
                 self._poison(f)
 
+    def set_diffuse_mode(self, mode):
+        self.st.diffuse_mode = mode
+
     def upload(self, image_id, array):
         self._owned(getattr(self.st, IMAGE_FIELD[image_id]))[...] = array
 

@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -35,10 +35,11 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
     from test_slab_step_gpu import drift, scene_params
 
     ctx = init_distributed(rank, backend="gloo")
-    params, cap = scene_params(size)
+    params, cap = scene_params(size, intended)
     slab = partition_z(size[2], world)[rank]
     comp = HostGlobalCompute(params, slab, cap, iters)
-    sim = SlabSimulation(params, cap, iters, ctx, compute=comp, grouped=grouped)
+    sim = SlabSimulation(params, cap, iters, ctx, compute=comp, grouped=grouped,
+                         diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
@@ -55,23 +56,24 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,steps,grouped", [
-    (2, (16, 12, 16), 6, 4, True), (3, (12, 10, 18), 5, 4, True),
-    (2, (16, 12, 16), 6, 4, False),   # the section list, one call per section
-    (2, (14, 12, 16), 6, 3, True),    # width not a multiple of 4: 09, 10, 11 stay separate
+@pytest.mark.parametrize("world,size,iters,steps,grouped,intended", [
+    (2, (16, 12, 16), 6, 4, True, False), (3, (12, 10, 18), 5, 4, True, False),
+    (2, (16, 12, 16), 6, 4, False, False),   # the section list, one call per section
+    (2, (14, 12, 16), 6, 3, True, False),    # width not a multiple of 4: 09, 10, 11 stay separate
+    (2, (16, 12, 16), 6, 3, True, True),    # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
 ])
-def test_slab_simulation_over_gloo_matches_oracle(world, size, iters, steps, grouped, tmp_path):
+def test_slab_simulation_over_gloo_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal
     from oracle_binding import OracleState
     from test_slab_step_gpu import drift, scene_params
 
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path)),
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
-    params, cap = scene_params(size)
-    st = OracleState(params, cap, iters)
+    params, cap = scene_params(size, intended)
+    st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
     st.run_init()
     st.run_step()
     st.velocities_1[...] = drift(st.shape)

@@ -21,8 +21,9 @@ def _free_port():
     return port
 
 
-def scene_params(size):
-    """Dam-break block placed across the slab faces: 8 particles per cell, z from 25 % to 75 %."""
+def scene_params(size, intended=False):
+    """Dam-break block placed across the slab faces: 8 particles per cell, z from 25 % to 75 %.
+    intended: a diffusion coefficient for 09_diffuse in FLUID_DIFFUSE_INTENDED mode."""
     import fluid_amd
     w, h, d = size
     p, _ = fluid_amd.dam_break_params(w, h, d)
@@ -34,6 +35,8 @@ def scene_params(size):
     p.particle_spawn_cube_size[:] = ext
     cap = res[0] * res[1] * res[2] + 37  # a few inactive slots at the end
     p.particle_compute_size[:] = (cap, 1)
+    if intended:
+        p.diffuse_k = 1.5
     p.time_delta = 0.04                  # bigger steps: particles cross slab faces within a few
     return p, cap
 
@@ -46,7 +49,7 @@ def drift(shape):
     return v
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -63,8 +66,9 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
     dist.init_process_group(backend="gloo")
     torch.cuda.set_device(0)
     ctx = DistContext(rank, world, torch.device("cuda", 0), "gloo")
-    params, cap = scene_params(size)
-    sim = SlabSimulation(params, cap, iters, ctx, transport="staged", grouped=grouped)
+    params, cap = scene_params(size, intended)
+    sim = SlabSimulation(params, cap, iters, ctx, transport="staged", grouped=grouped,
+                         diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
@@ -83,22 +87,23 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,steps,grouped", [
-    (2, (32, 24, 16), 12, 6, True), (3, (64, 16, 24), 9, 5, True),
-    (2, (32, 24, 16), 12, 4, False),  # the section list, one kernel per section
-    (2, (30, 24, 16), 12, 4, True),   # width not a multiple of 4
+@pytest.mark.parametrize("world,size,iters,steps,grouped,intended", [
+    (2, (32, 24, 16), 12, 6, True, False), (3, (64, 16, 24), 9, 5, True, False),
+    (2, (32, 24, 16), 12, 4, False, False),  # the section list, one kernel per section
+    (2, (30, 24, 16), 12, 4, True, False),   # width not a multiple of 4
+    (2, (32, 24, 16), 12, 4, True, True),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
 ])
-def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, tmp_path):
+def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal
     from oracle_binding import OracleState
 
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path)),
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
-    params, cap = scene_params(size)
-    st = OracleState(params, cap, iters)
+    params, cap = scene_params(size, intended)
+    st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
     st.run_init()
     st.run_step()
     st.velocities_1[...] = drift(st.shape)

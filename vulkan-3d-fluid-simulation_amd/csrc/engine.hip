@@ -840,8 +840,8 @@ int run_section_impl(fluid_ctx* c, int section) {
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);
             break;
         case FLUID_SEC_09_DIFFUSE:
-            if (c->diffuse_mode == FLUID_DIFFUSE_INTENDED && c->is_slab)
-                return slab_unsupported(c, "09_diffuse in FLUID_DIFFUSE_INTENDED mode");
+            // intended mode is a 7-point stencil on VELOCITIES_2: on a Z slab the caller exchanges one
+            // ghost plane of VELOCITIES_2 per side before this section
             if (c->diffuse_mode == FLUID_DIFFUSE_INTENDED)
                 hipLaunchKernelGGL(k09_diffuse<true>, grid, block, 0, c->stream, T, V2, V1, g, pk);
             else

@@ -208,6 +208,9 @@ class GpuSlabCompute:
     def run_section_group(self, first: str, count: int):
         self.engine.run_section_group(first, count)
 
+    def set_diffuse_mode(self, mode: int):
+        self.engine.set_diffuse_mode(mode)
+
     # ---- full step on slabs -----------------------------------------------------------------------
     IMAGE_GHOST = E.FluidEngine.IMAGE_GHOST_PLANES
 
@@ -707,10 +710,13 @@ class SlabSimulation:
 
     def __init__(self, params: FluidParams, particle_capacity: int, iterations: int, ctx: DistContext,
                  compute=None, transport: str = "direct", halo_depth: int = 8, grouped: bool = True,
-                 overlap: Optional[bool] = None):
+                 overlap: Optional[bool] = None, diffuse_mode: int = E.DIFFUSE_REFERENCE_EXACT):
         # grouped: 04+05, 07+08 and 09+10+11 as single passes (include/fluid_engine.h:
         # fluid_run_section_group); 09+10+11 needs fluid_size.x % 4 == 0
         self.grouped = grouped
+        # E.DIFFUSE_INTENDED: 09 is the 7-point diffusion the shader meant, which needs a
+        # ghost plane of VELOCITIES_2 per side and runs 09, 10, 11 one by one
+        self.diffuse_mode = diffuse_mode
         self.params = params
         self.ctx = ctx
         self.size = params.size
@@ -720,6 +726,8 @@ class SlabSimulation:
         self.compute = compute or GpuSlabCompute(params, slab, ctx.device,
                                                  particle_capacity=particle_capacity,
                                                  pressure_iterations=iterations)
+        if diffuse_mode != E.DIFFUSE_REFERENCE_EXACT:
+            self.compute.set_diffuse_mode(diffuse_mode)
         self.pressure = SlabPressureSolver(self.size, iterations, ctx, self.compute, slab,
                                            transport=transport, halo_depth=halo_depth)
         if overlap is not None:  # else SlabPressureSolver's default (FLUID_SLAB_OVERLAP)
@@ -762,10 +770,13 @@ class SlabSimulation:
         else:
             c.run_section("07_advect")
             c.run_section("08_forces")
-        if self.grouped and self.size[0] % 4 == 0:
+        intended = self.diffuse_mode == E.DIFFUSE_INTENDED
+        if self.grouped and self.size[0] % 4 == 0 and not intended:
             x(E.VELOCITIES_2, 1)                       # 11, on what 10 makes of V2 at z+1
             c.run_section_group("09_diffuse", 3)
         else:
+            if intended:
+                x(E.VELOCITIES_2, 1)                   # the diffusion stencil reads V2 at z-1, z+1
             c.run_section("09_diffuse")
             c.run_section("10_solids")
             x(E.VELOCITIES_1, 1)                       # 11 reads V1 at z+1
