@@ -898,3 +898,46 @@ def test_red_black_sor_full_steps_and_convergence():
     err = {k: np.abs(v - sol["converged"])[wet].max() for k, v in sol.items()}
     assert err["jacobi 200"] > 0.5 * np.abs(sol["converged"][wet]).max()   # 200 sweeps: not even close
     assert err["sor 100"] < 0.1 * err["jacobi 200"], err
+
+
+@pytest.mark.parametrize("seed,size", [(1, (512, 48, 96)), (2, (768, 32, 64)), (3, (256, 48, 96)),
+                                       (4, (1024, 24, 64))])
+def test_moving_blob_all_step_optimisations_equal_the_section_list(seed, size):
+    """A blob of water drifting through a wide, mostly empty grid for 14 steps: the default fluid_run_step
+    (grouped passes, quiet bricks, early test, box-shaped and x-windowed Jacobi launches, LDS sampler)
+    against the plain section list with every cell processed — images and particles bit-identical after
+    every step while the blob crosses brick, window and tile boundaries."""
+    w, h, d = size
+    rng = np.random.default_rng(seed)
+    cap = 6000
+    p = default_params(w, h, d, cap)
+    p.time_delta = 0.05
+    p.particle_compute_size[:] = (cap, 1)
+    centre = np.array([0.35 * w, 0.5 * h, 0.4 * d], np.float32)
+    particles = np.zeros((cap, 4), np.float32)
+    particles[:, :3] = centre + rng.uniform(-1, 1, (cap, 3)).astype(np.float32) * \
+        np.array([min(40.0, 0.1 * w), 3.0, 4.0], np.float32)
+    particles[:, 3] = 1.0
+    drift = np.zeros((d, h, w, 4), np.float32)
+    drift[..., 0] = 45.0 + 10.0 * seed     # cells per second along x: > 2 cells per step
+    drift[..., 2] = 6.0
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=20) as a, \
+            fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=20) as b:
+        b.set_option(E.OPT_STEP_FUSION, 1)
+        b.set_option(E.OPT_JACOBI_FUSE, 1)
+        b.set_option(E.OPT_ADVECT_KERNEL, 1)
+        for eng in (a, b):
+            eng.run_init()
+            eng.upload_particles(particles)
+            eng.run_step()                       # cells become active; 05 replaces their velocities
+            eng.upload_image(E.VELOCITIES_1, drift)
+        quiet_seen = 0
+        for k in range(14):
+            a.run_step()
+            b.run_step()
+            quiet_seen = max(quiet_seen, a.get_stat(E.STAT_QUIET_BRICKS))
+            for name, img in IMAGE_FIELDS.items():
+                assert_bit_equal(a.download_image(img), b.download_image(img), f"step {k} {name}")
+            assert_bit_equal(a.download_particles(), b.download_particles(), f"step {k} particles")
+        moved = a.download_particles()[:, 0].mean() - particles[:, 0].mean()
+        assert moved > 10.0 and quiet_seen > 0   # the blob travelled, and bricks did go quiet
