@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -22,6 +23,8 @@ namespace fluid {
 static inline int pick_zchunk(int row_groups, int depth, int cus) {
     // cached per geometry (a slab loop alternates between a few depths; the model costs ~1 ms)
     static std::map<std::tuple<int, int, int>, int> cache;
+    static std::mutex cache_mutex;  // contexts of different host threads share this table
+    std::lock_guard<std::mutex> lock(cache_mutex);
     const auto key = std::make_tuple(row_groups, depth, cus);
     const auto hit = cache.find(key);
     if (hit != cache.end()) return hit->second;
@@ -71,13 +74,17 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                             float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
                             int part_lo, int part_hi) {
-    static bool attr_set = false;  // per process and instantiation; the attribute is per function
+    // the dynamic-LDS limit is an attribute of the function on a device: once per instantiation and
+    // device (a process may hold contexts on several)
+    static bool attr_set[64] = {};
     const size_t lds = fused_lds_bytes(NT);
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     constexpr int TY = FUSED_WAVES / NT - 2;
     FusedRange r = rg;
