@@ -106,8 +106,21 @@ def cpu_baseline_jacobi(size, iters_hint):
                   f"({dt:.1f} s, {cells_per_s / 1e6:.1f} Mcells/s), scaled by cell count to "
                   f"{w}x{h}x{d}",
         "cells_per_s": cells_per_s,
+        "ms_per_sweep": 1e3 * (w * h * d) / cells_per_s,
+        "cpu_model": host_cpu_model(),
         "full_step_c1": cpu_vs_gpu_full_step_c1(),
     }
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_vs_gpu_full_step_c1():
