@@ -258,4 +258,64 @@ __global__ void k12_sor_colour(const uint8_t* __restrict__ t, const float* __res
     pr[id] = old + t2;
 }
 
+// The same with four cells per thread (fluid_size.x % 4 == 0): the quad's two cells of the colour are
+// updated, the other two are written back unchanged (they belong to this thread's quad, so nobody else
+// writes them in this launch); pressures and divergences move as float4 rows, types as 4-byte words.
+__global__ void k12_sor_colour_v4(const uint8_t* __restrict__ t, const float* __restrict__ div,
+                                  float* __restrict__ pr, GridK g, ParamsK p, float omega, int colour) {
+    FLUID_V4_THREAD();
+    const int lz = blockIdx.z;
+    const int64_t id = cidx(g, x, y, lz);
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+    const uint32_t w4 = p.t_water * 0x01010101u;
+    // any water cell of this colour in the quad?  (cheap exit for dry quads)
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        any = any || (byte_at(c, i) == p.t_water && ((x + i + y + g.z0 + lz + colour) & 1) == 0);
+    (void)w4;
+    if (!any) return;
+    const uint32_t typ = ld_types4(t, g, x, y + 1, lz), tym = ld_types4(t, g, x, y - 1, lz);
+    const uint32_t tzp = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz + 1));
+    const uint32_t tzm = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz - 1));
+    const uint32_t tl = x > 0 ? (uint32_t)t[id - 1] : 0u, tr = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prow = [&](int ny) {
+        return (unsigned)ny < (unsigned)g.H ? *reinterpret_cast<const float4*>(pr + cidx(g, x, ny, lz)) : zero;
+    };
+    const float4 pc = *reinterpret_cast<const float4*>(pr + id);
+    const float4 pyp = prow(y + 1), pym = prow(y - 1);
+    const float4 pzp = *reinterpret_cast<const float4*>(pr + cidx(g, x, y, lz + 1));
+    const float4 pzm = *reinterpret_cast<const float4*>(pr + cidx(g, x, y, lz - 1));
+    const float pl = x > 0 ? pr[id - 1] : 0.0f, prr = x + 4 < g.W ? pr[id + 4] : 0.0f;
+    const float4 d4 = *reinterpret_cast<const float4*>(div + id);
+    const float cc[4] = {pc.x, pc.y, pc.z, pc.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float a_yp[4] = {pyp.x, pyp.y, pyp.z, pyp.w}, a_ym[4] = {pym.x, pym.y, pym.z, pym.w};
+    const float a_zp[4] = {pzp.x, pzp.y, pzp.z, pzp.w}, a_zm[4] = {pzm.x, pzm.y, pzm.z, pzm.w};
+    float out[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (byte_at(c, i) != p.t_water || ((x + i + y + g.z0 + lz + colour) & 1) != 0) continue;
+        int aii = 0;
+        float s = ((dd[i] * p.rho) * p.dx) / p.dt;
+        auto nb = [&](uint32_t ty, float q) {
+            if (ty != p.t_solid) {
+                s = s - (ty == p.t_water ? q : p.p_air);
+                aii++;
+            }
+        };
+        nb(i == 3 ? tr : byte_at(c, i == 3 ? 3 : i + 1), i == 3 ? prr : cc[i == 3 ? 3 : i + 1]);  // +x
+        nb(byte_at(typ, i), a_yp[i]);                                                             // +y
+        nb(byte_at(tzp, i), a_zp[i]);                                                             // +z
+        nb(i == 0 ? tl : byte_at(c, i == 0 ? 0 : i - 1), i == 0 ? pl : cc[i == 0 ? 0 : i - 1]);    // -x
+        nb(byte_at(tym, i), a_ym[i]);                                                             // -y
+        nb(byte_at(tzm, i), a_zm[i]);                                                             // -z
+        const float gs = -s / (float)aii;
+        const float d = gs - cc[i];
+        const float t2 = omega * d;
+        out[i] = cc[i] + t2;
+    }
+    *reinterpret_cast<float4*>(pr + id) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 }  // namespace fluid

@@ -45,6 +45,11 @@ void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, cons
 
 void k12_launch_sor_colour(hipStream_t s, const uint8_t* t, const float* div, float* pr, const GridK& g,
                            const ParamsK& p, float omega, int colour) {
+    if (g.W % 4 == 0) {
+        hipLaunchKernelGGL(k12_sor_colour_v4, v4_grid(g, g.Dl), v4_block(), 0, s, t, div, pr, g, p, omega,
+                           colour);
+        return;
+    }
     const int half = (g.W + 1) / 2;
     hipLaunchKernelGGL(k12_sor_colour, dim3((half + 63) / 64, (g.H + 3) / 4, g.Dl), dim3(64, 4, 1), 0, s, t,
                        div, pr, g, p, omega, colour);
