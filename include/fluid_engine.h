@@ -437,6 +437,10 @@ typedef enum fluid_option {
                                    /* straight from global memory                                    */
     FLUID_OPT_SURFACE_KERNEL = 5,  /* 18_diffuse_float_densities: 0 = z-marching kernel (default), 1 = four */
                                    /* cells per thread, one plane per workgroup                         */
+    FLUID_OPT_LAUNCH_BOX = 6,      /* pressure loop on a sparse scene: 0 = launches cover only the box / x  */
+                                   /* window that holds the water, which costs ONE stream synchronisation  */
+                                   /* per step (the host reads 28 bytes); 1 = full-grid launches, every    */
+                                   /* call of fluid_run_step stays asynchronous                            */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

@@ -927,6 +927,7 @@ def test_moving_blob_all_step_optimisations_equal_the_section_list(seed, size):
         b.set_option(E.OPT_STEP_FUSION, 1)
         b.set_option(E.OPT_JACOBI_FUSE, 1)
         b.set_option(E.OPT_ADVECT_KERNEL, 1)
+        b.set_option(E.OPT_LAUNCH_BOX, 1)
         for eng in (a, b):
             eng.run_init()
             eng.upload_particles(particles)

@@ -688,7 +688,10 @@ int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
     if (iterations == 0) return FLUID_OK;
     int rc = loop_begin(c);
     const bool fuse = fuse_enabled(c) && !c->is_slab;  // a slab needs its halos between launches
-    if (rc == FLUID_OK && fuse && iterations >= 16) rc = refresh_box(c);
+    // shaping the launches to the water costs one stream synchronisation per rebuilt mask; a caller that
+    // wants fluid_run_step to stay fully asynchronous turns it off (FLUID_OPT_LAUNCH_BOX = 1)
+    if (rc == FLUID_OK && fuse && iterations >= 16 && c->opt[FLUID_OPT_LAUNCH_BOX] == 0)
+        rc = refresh_box(c);
     while (rc == FLUID_OK && c->loop_k < iterations) {
         const uint32_t left = iterations - c->loop_k;
         if (fuse && left >= 2)

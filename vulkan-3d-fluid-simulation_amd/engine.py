@@ -60,6 +60,7 @@ OPT_STEP_FUSION = 2
 OPT_QUIET_BRICKS = 3
 OPT_ADVECT_KERNEL = 4
 OPT_SURFACE_KERNEL = 5
+OPT_LAUNCH_BOX = 6
 STAT_BRICKS, STAT_QUIET_BRICKS = 0, 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
