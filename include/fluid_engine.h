@@ -357,11 +357,18 @@ int fluid_pressure_loop_end(fluid_ctx* ctx);
  *       wait for the receives, then EDGES.
  * At a domain face there is no edge: pass the plane range's natural end there (e.g. INT32_MIN /
  * INT32_MAX; the engine clips). */
+/* FLUID_OPT_EDGE_STREAM = 1: the EDGES launch goes to a second, high-priority stream of the context
+ * (fluid_pressure_loop_edge_stream) and runs BESIDE the INTERIOR launch; the engine orders both after the
+ * work that preceded the pass and lets the main stream wait for the edges when the pass completes.  The
+ * caller then orders its exchange against THAT stream: start it after an event recorded on the edge stream
+ * once EDGES is enqueued (pass before the exchange), and make the edge stream wait for the receives before
+ * enqueueing EDGES (pass after it). */
 #define FLUID_LOOP_PART_EDGES 1
 #define FLUID_LOOP_PART_INTERIOR 2
 int fluid_pressure_loop_advance_part(fluid_ctx* ctx, int keep_intermediate, int part,
                                      int32_t interior_begin, int32_t interior_end,
                                      int* written_buffer);
+int fluid_pressure_loop_edge_stream(fluid_ctx* ctx, void** hip_stream);
 int fluid_pressure_loop_plane_ptr(fluid_ctx* ctx, int which, int32_t plane, void** device_ptr,
                                   uint64_t* bytes);
 
@@ -441,6 +448,9 @@ typedef enum fluid_option {
                                    /* window that holds the water, which costs ONE stream synchronisation  */
                                    /* per step (the host reads 28 bytes); 1 = full-grid launches, every    */
                                    /* call of fluid_run_step stays asynchronous                            */
+    FLUID_OPT_EDGE_STREAM = 7,     /* split passes of the explicit loop API: 0 = both launches on the       */
+                                   /* context's stream (default), 1 = EDGES on a second stream (see        */
+                                   /* fluid_pressure_loop_advance_part)                                    */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);

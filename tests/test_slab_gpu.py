@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir):
+def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir, edge=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -43,7 +43,7 @@ def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir):
     w, h, d = size
     st = random_state(size, seed=seed, iters=iters)
     slab = partition_z(d, world)[rank]
-    comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant)
+    comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant, edge_stream=edge)
     solver = SlabPressureSolver(size, iters, ctx, comp, slab, transport="staged", halo_depth=halo)
     z0, n = slab
     comp.upload(E.CELL_TYPES, st.cell_types[z0:z0 + n])
@@ -62,26 +62,28 @@ def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,variant,halo", [
-    (2, (64, 24, 20), 6, 0, 2),     # working-buffer loop, two sweeps per exchange
-    (2, (64, 24, 20), 21, 0, 8),    # eight sweeps per exchange (redundant ghost-region compute), odd tail
-    (2, (64, 24, 40), 12, 0, 6),    # six
-    (3, (260, 9, 11), 5, 0, 8),     # slabs of 4/4/3 planes clip the halo to 2
-    (3, (256, 12, 13), 8, 7, 4),    # explicit fast-path kernel option
-    (2, (64, 24, 20), 7, 2, 8),     # general kernel on the images: one plane per sweep
-    (2, (17, 9, 8), 4, 0, 8),       # width not a multiple of 4: falls back to the images as well
-    (2, (64, 24, 40), 21, 0, 8),    # slabs of 20 planes, halo 8: split passes around the exchanges
-    (3, (256, 12, 30), 14, 0, 4),   # three ranks, halo 4 on slabs of 10 planes, split passes
-    (2, (512, 7, 24), 12, 0, 4),    # two x tiles per row
+@pytest.mark.parametrize("world,size,iters,variant,halo,edge", [
+    (2, (64, 24, 20), 6, 0, 2, False),     # working-buffer loop, two sweeps per exchange
+    (2, (64, 24, 20), 21, 0, 8, False),    # eight sweeps per exchange (redundant ghost-region compute), odd tail
+    (2, (64, 24, 40), 12, 0, 6, False),    # six
+    (3, (260, 9, 11), 5, 0, 8, False),     # slabs of 4/4/3 planes clip the halo to 2
+    (3, (256, 12, 13), 8, 7, 4, False),    # explicit fast-path kernel option
+    (2, (64, 24, 20), 7, 2, 8, False),     # general kernel on the images: one plane per sweep
+    (2, (17, 9, 8), 4, 0, 8, False),       # width not a multiple of 4: falls back to the images as well
+    (2, (64, 24, 40), 21, 0, 8, False),    # slabs of 20 planes, halo 8: split passes around the exchanges
+    (3, (256, 12, 30), 14, 0, 4, False),   # three ranks, halo 4 on slabs of 10 planes, split passes
+    (2, (512, 7, 24), 12, 0, 4, False),    # two x tiles per row
+    (2, (64, 24, 40), 21, 0, 8, True),    # the same with the EDGES launches on the second engine stream
+    (3, (256, 12, 30), 14, 0, 4, True),
 ])
-def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, tmp_path):
+def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, edge, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal, random_state
 
     seed = 33
     mp.start_processes(_worker, args=(world, _free_port(), size, iters, seed, variant, halo,
-                                      str(tmp_path)),
+                                      str(tmp_path), edge),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     st = random_state(size, seed=seed, iters=iters)

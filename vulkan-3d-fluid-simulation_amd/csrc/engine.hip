@@ -127,6 +127,9 @@ struct fluid_ctx {
                              // every sweep, restored by the caller's halo exchange)
     int loop_aux_halo = 0;   // ... of mask / b_i (fixed for the loop)
     bool loop_ghost_bg = false;  // ghost planes of the other two buffers hold their constants
+    hipStream_t edge_stream = nullptr;  // FLUID_OPT_EDGE_STREAM: EDGES launches of split passes
+    hipEvent_t ev_pass_start = nullptr, ev_edges_done = nullptr;
+    bool edges_pending = false;
     int loop_part_done = 0;      // FUSED_EDGES / FUSED_INTERIOR: that half of a split pass is launched
     bool loop_part_keep = false;
     int loop_part_lo = 0, loop_part_hi = 0;
@@ -577,14 +580,25 @@ int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1)
 // two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
 // j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
 int launch_fused(fluid_ctx* c, int src, int dst, int mid, int part = FUSED_WHOLE, int part_lo = 0,
-                 int part_hi = 0) {
+                 int part_hi = 0, hipStream_t stream = nullptr) {
     const bool lo = c->g.z0 > 0, hi = c->g.z0 + c->g.Dl < c->g.Dg;  // neighbouring slabs
-    HIP_TRY(c, k12_launch_canon2(c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
+    HIP_TRY(c, k12_launch_canon2(stream ? stream : c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
                                  mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
                                  oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
                                  lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0,
                                  c->box, part, part_lo, part_hi));
     HIP_TRY(c, hipGetLastError());
+    return FLUID_OK;
+}
+
+// second stream for the EDGES launches of split passes (FLUID_OPT_EDGE_STREAM), created on first use
+int ensure_edge_stream(fluid_ctx* c) {
+    if (c->edge_stream) return FLUID_OK;
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(c, hipStreamCreateWithPriority(&c->edge_stream, hipStreamNonBlocking, hi));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pass_start, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_edges_done, hipEventDisableTiming));
     return FLUID_OK;
 }
 
@@ -649,9 +663,30 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int
         const int mid = keep_mid ? other_buffer(cur, dst) : -1;
         rc = ensure_background(c, dst);
         if (rc == FLUID_OK && mid >= 0) rc = ensure_background(c, mid);
-        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid, part, part_lo, part_hi);
+        // FLUID_OPT_EDGE_STREAM: the EDGES launch of a split pass goes to a second, high-priority stream so
+        // that it runs beside the INTERIOR launch instead of before / after it.  Both read the source
+        // buffer and write disjoint planes of the destination; both start after whatever preceded the
+        // pass on the main stream (ev_pass_start); the main stream picks the edges up again at commit.
+        hipStream_t where = nullptr;
+        if (part != FUSED_WHOLE && c->opt[FLUID_OPT_EDGE_STREAM] != 0 && rc == FLUID_OK) {
+            rc = ensure_edge_stream(c);
+            if (rc == FLUID_OK && !commit) HIP_TRY(c, hipEventRecord(c->ev_pass_start, c->stream));
+            if (rc == FLUID_OK && part == FUSED_EDGES) {
+                HIP_TRY(c, hipStreamWaitEvent(c->edge_stream, c->ev_pass_start, 0));
+                where = c->edge_stream;
+            }
+        }
+        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid, part, part_lo, part_hi, where);
+        if (where && rc == FLUID_OK) {
+            HIP_TRY(c, hipEventRecord(c->ev_edges_done, c->edge_stream));
+            c->edges_pending = true;
+        }
         if (written) *written = dst;
         if (!commit) return rc;
+        if (c->edges_pending) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_edges_done, 0));
+            c->edges_pending = false;
+        }
         c->loop_prev = mid;
         c->loop_cur = dst;
         c->loop_k += 2;
@@ -1216,6 +1251,9 @@ void fluid_destroy(fluid_ctx* c) {
         if (s.stop) (void)hipEventDestroy(s.stop);
     }
     if (c->brick_count_host) (void)hipHostFree(c->brick_count_host);
+    if (c->ev_pass_start) (void)hipEventDestroy(c->ev_pass_start);
+    if (c->ev_edges_done) (void)hipEventDestroy(c->ev_edges_done);
+    if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1478,6 +1516,16 @@ int fluid_pressure_loop_advance_part(fluid_ctx* c, int keep_intermediate, int pa
                       interior_end);
     int rc2 = tm.end();  // two launches = two timer calls = the pass's two sweeps in sec_calls
     return rc ? rc : rc2;
+}
+
+int fluid_pressure_loop_edge_stream(fluid_ctx* c, void** hip_stream) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!hip_stream) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_edge_stream(c);
+    if (rc) return rc;
+    *hip_stream = c->edge_stream;
+    return FLUID_OK;
 }
 
 int fluid_pressure_loop_halo_exchanged(fluid_ctx* c, uint32_t depth, uint32_t aux_depth) {

@@ -61,6 +61,7 @@ OPT_QUIET_BRICKS = 3
 OPT_ADVECT_KERNEL = 4
 OPT_SURFACE_KERNEL = 5
 OPT_LAUNCH_BOX = 6
+OPT_EDGE_STREAM = 7
 STAT_BRICKS, STAT_QUIET_BRICKS = 0, 1
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
@@ -79,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_notify_ghost_planes_written", "fluid_get_stat", "fluid_pressure_residual",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
-    "fluid_pressure_loop_advance_part",
+    "fluid_pressure_loop_advance_part", "fluid_pressure_loop_edge_stream",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
     "fluid_get_geometry", "fluid_set_option",
@@ -165,6 +166,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
         "fluid_pressure_loop_advance_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_int)]),
+        "fluid_pressure_loop_edge_stream": (C.c_int, [vp, C.POINTER(vp)]),
         "fluid_pressure_loop_halo_exchanged": (C.c_int, [vp, u32, u32]),
         "fluid_pressure_loop_end": (C.c_int, [vp]),
         "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
@@ -464,6 +466,12 @@ class FluidEngine:
         self._check(self._lib.fluid_pressure_loop_advance_part(
             self._h, 1 if keep_intermediate else 0, part, lo, hi, C.byref(written)))
         return int(written.value)
+
+    def pressure_loop_edge_stream(self) -> int:
+        """hipStream_t (as an integer) that EDGES launches use under OPT_EDGE_STREAM."""
+        s = C.c_void_p()
+        self._check(self._lib.fluid_pressure_loop_edge_stream(self._h, C.byref(s)))
+        return int(s.value or 0)
 
     def pressure_loop_halo_exchanged(self, depth: int, aux_depth: int = 0):
         self._check(self._lib.fluid_pressure_loop_halo_exchanged(self._h, depth, aux_depth))

@@ -75,7 +75,7 @@ class GpuSlabCompute:
     stream, which is also the stream the NCCL ops synchronise with."""
 
     def __init__(self, params: FluidParams, slab: Tuple[int, int], device, pressure_kernel: int = 0,
-                 particle_capacity: int = 0, pressure_iterations: int = 200):
+                 particle_capacity: int = 0, pressure_iterations: int = 200, edge_stream: bool = False):
         import torch
 
         self.torch = torch
@@ -99,6 +99,13 @@ class GpuSlabCompute:
             slab=slab, stream=self.stream.cuda_stream,
             arena=base + self._pad, arena_bytes=nbytes)
         self.engine.set_option(E.OPT_PRESSURE_KERNEL, pressure_kernel)
+        # FLUID_OPT_EDGE_STREAM: the EDGES launches of split passes run on a second engine stream beside
+        # the INTERIOR launches; exchanges are then ordered against that stream (comm_scope / comm_join)
+        self.edge_ext = None
+        if edge_stream or os.environ.get("FLUID_SLAB_EDGE_STREAM") == "1":
+            self.engine.set_option(E.OPT_EDGE_STREAM, 1)
+            self.edge_ext = torch.cuda.ExternalStream(self.engine.pressure_loop_edge_stream(),
+                                                      device=device)
         self._base = base
         # working-buffer loop (fluid_pressure_loop_*) when the engine offers it for this grid
         self.fast = params.size[0] % 4 == 0 and pressure_kernel in (0, 5, 6, 7)
@@ -176,6 +183,10 @@ class GpuSlabCompute:
         ev = torch.cuda.Event()
         ev.record(self.stream)
         self.comm_stream.wait_event(ev)
+        if self.edge_ext is not None:  # ... and on the edge stream (the planes to send come from there)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.edge_ext)
+            self.comm_stream.wait_event(ev2)
         return torch.cuda.stream(self.comm_stream)
 
     def comm_mark(self):
@@ -185,8 +196,10 @@ class GpuSlabCompute:
         return ev
 
     def comm_join(self, mark):
-        """Launches on the compute stream from here on come after the exchange."""
+        """Launches on the compute stream (and the edge stream) from here on come after the exchange."""
         self.stream.wait_event(mark)
+        if self.edge_ext is not None:
+            self.edge_ext.wait_event(mark)
 
     def loop_end(self):
         if self.fast:
@@ -476,23 +489,26 @@ class SlabPressureSolver:
                 plan.append((True, make_planes(n - width, width), self.hi))
                 plan.append((False, make_planes(n, width), self.hi))
             self._plans[key] = plan
-        if self.transport == "staged":
-            # through host tensors, synchronously (t.cpu() waits for the compute stream): rehearses
-            # the schedule of the GPU path over gloo on a box with one GPU; nothing overlaps
-            staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
-                      for snd, t, peer in plan]
-            ops = [dist.P2POp(dist.isend if snd else dist.irecv, h, peer)
-                   for snd, h, _, peer in staged]
-            for work in dist.batch_isend_irecv(ops):
-                work.wait()
-            for snd, h, t, _ in staged:
-                if not snd:
-                    t.copy_(h)
-            return None
         scope = self.compute.comm_scope() if overlapped else None
         if scope is not None:
             scope.__enter__()
         try:
+            if self.transport == "staged":
+                # through host tensors, synchronously (t.cpu() waits for the current stream, which inside
+                # the scope is the communication stream, ordered after the launches that produce the
+                # planes): rehearses the schedule of the GPU path over gloo on a box with one GPU
+                staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
+                          for snd, t, peer in plan]
+                ops = [dist.P2POp(dist.isend if snd else dist.irecv, h, peer)
+                       for snd, h, _, peer in staged]
+                for work in dist.batch_isend_irecv(ops):
+                    work.wait()
+                for snd, h, t, _ in staged:
+                    if not snd:
+                        t.copy_(h)
+                if not overlapped:
+                    return None
+                return ("overlapped", [], self.compute.comm_mark())
             if self.transport == "loopback":
                 # single-process rehearsal of one rank's work (tools/slab_rank_sim.py): every receive
                 # is filled by a device copy of a send buffer of the same size; no communicator
