@@ -43,8 +43,10 @@ def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir, edge=F
     w, h, d = size
     st = random_state(size, seed=seed, iters=iters)
     slab = partition_z(d, world)[rank]
-    comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant, edge_stream=edge)
+    comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant, edge_stream=edge is True)
     solver = SlabPressureSolver(size, iters, ctx, comp, slab, transport="staged", halo_depth=halo)
+    if edge == "before":   # only the pass before an exchange is split
+        solver.overlap = "before"
     z0, n = slab
     comp.upload(E.CELL_TYPES, st.cell_types[z0:z0 + n])
     comp.upload(E.DIVERGENCES, st.divergences[z0:z0 + n])
@@ -75,6 +77,7 @@ def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir, edge=F
     (2, (512, 7, 24), 12, 0, 4, False),    # two x tiles per row
     (2, (64, 24, 40), 21, 0, 8, True),    # the same with the EDGES launches on the second engine stream
     (3, (256, 12, 30), 14, 0, 4, True),
+    (2, (64, 24, 40), 21, 0, 8, "before"),  # half-overlapped schedule
 ])
 def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, edge, tmp_path):
     import torch.multiprocessing as mp

@@ -423,9 +423,11 @@ class SlabPressureSolver:
         # per sweep, h times fewer messages and host round trips).  Clipped to what the compute
         # backend and the slab thickness allow; even, so sweeps can go in pairs.
         self.halo_depth = halo_depth
-        # run halo exchanges beside the passes that do not need them (solve()); FLUID_SLAB_OVERLAP=0
-        # turns it off
-        self.overlap = os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0"
+        # run halo exchanges beside the passes that do not need them (solve()): True = split the pass
+        # before and the pass after each exchange, "before" = only the pass before it, False = exchanges
+        # in line.  FLUID_SLAB_OVERLAP=0 / before / 1 forces one; bench.py --gpus N measures all three.
+        env = os.environ.get("FLUID_SLAB_OVERLAP", "1")
+        self.overlap = False if env == "0" else ("before" if env == "before" else True)
         # transport "direct": the communicator addresses the planes where they live (RCCL on
         # device memory, gloo on host memory).  "staged": bounce through host tensors — only for
         # rehearsing the GPU slab path over gloo on a box with a single GPU (tests).
@@ -608,7 +610,12 @@ class SlabPressureSolver:
             left = n - k - sweeps
             next_sweeps = 2 if (pair and left >= 2) else min(left, 1)
             valid_after = valid - 2 if sweeps == 2 else 0
-            if pending is not None:
+            if pending is not None and self.overlap == "before":
+                # half the overlap: only the pass before the exchange was split; wait, then a whole pass
+                self._finish_plan(pending)
+                pending = None
+                cur = c.loop_advance(k, sweeps, keep)
+            elif pending is not None:
                 # first pass after the exchange started: valid == h here (reported at the start)
                 c.loop_advance(k, 2, keep, "interior", after)
                 self._finish_plan(pending)
@@ -681,9 +688,9 @@ class SlabPressureSolver:
         import torch.distributed as dist
 
         if not self.overlap or self.ctx.world == 1 or "FLUID_SLAB_OVERLAP" in os.environ:
-            return {"used": bool(self.overlap and self.ctx.world > 1), "probed": False}
+            return {"used": self.overlap if self.ctx.world > 1 else False, "probed": False}
         times = {}
-        for mode in (False, True):
+        for mode in (False, "before", True):
             self.overlap = mode
             self.step()
             self.compute.sync()
@@ -694,8 +701,9 @@ class SlabPressureSolver:
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.ctx.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             times[mode] = float(t.item())
-        self.overlap = times[True] < times[False]
-        return {"used": self.overlap, "probed": True, "step_ms_inline": 1e3 * times[False],
+        self.overlap = min(times, key=times.get)  # the same on every rank: the times are the all-reduced MAX
+        return {"used": self.overlap if self.overlap else False, "probed": True,
+                "step_ms_inline": 1e3 * times[False], "step_ms_overlap_before": 1e3 * times["before"],
                 "step_ms_overlapped": 1e3 * times[True]}
 
     def gather_pressures(self):
