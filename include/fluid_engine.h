@@ -31,8 +31,12 @@
  *       PARTICLES_BUF    vec4[particle_capacity], xyz + w = active flag (:72)
  *   - Out-of-bounds image loads return 0, out-of-bounds stores/atomics are dropped (Vulkan
  *     robust-image semantics the shaders rely on).
- *   - All run_* calls enqueue asynchronously on the context's in-order HIP stream; stream order
- *     replaces the reference's image barriers.  fluid_sync() is the fence.
+ *   - run_* calls enqueue on the context's in-order HIP stream and return; stream order replaces the
+ *     reference's image barriers.  fluid_sync() is the fence.  ONE exception by default: a pressure loop
+ *     of >= 16 iterations on a whole-grid context (hence fluid_run_step) waits once, before its first
+ *     sweep, for 28 bytes that say where the water is, so that the sweeps are launched over that box only
+ *     (the work enqueued before it — at most the step's sections 01a..11 — has executed when the call
+ *     returns).  FLUID_OPT_LAUNCH_BOX = 1 removes the wait: full-grid launches, every call asynchronous.
  *   - Every call returns 0 on success or a negative fluid_status; fluid_last_error() gives text.
  *   - One host thread per context.
  */
@@ -465,6 +469,12 @@ int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
  * them across ranks with max / sum.  Reduced per wavefront with wave64 shuffles, one atomic each. */
 int fluid_pressure_residual(fluid_ctx* ctx, int image_id, float* max_abs, double* sum_squares,
                             uint64_t* water_cells);
+
+/* Number of fp32 words of an image's owned planes that are inf or NaN (synchronises the stream).  The
+ * reference never checks: a WATER cell enclosed by SOLID on all six sides has aii = 0 (pressure.comp:53-62),
+ * its pressure becomes inf / NaN and 13_fix_divergence carries that into the velocities.  Float images only
+ * (VELOCITIES_1/2 count all four components, PRESSURES_1/2, DIVERGENCES, PARTICLE_DENSITIES_FLOAT_1/2). */
+int fluid_count_nonfinite(fluid_ctx* ctx, int image_id, uint64_t* count);
 
 /* Diagnostics (synchronises the stream). */
 typedef enum fluid_stat {

@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+# FLUID_ORACLE_LIB: another build of the same source, e.g. oracle/liboracle_asan.so (tests/test_oracle_asan.py)
+ORACLE_LIB = os.environ.get("FLUID_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 import sys  # noqa: E402
 

@@ -171,6 +171,13 @@ def test_pressure_walled_in_cell_produces_the_same_inf_nan():
             s2.solve_pressure(3)
             assert np.isnan(s2.pressures_2[5, 5, 5]) and np.isinf(s2.pressures_2[10, 10, 10])
             assert_state_equal(eng, s2, fields=["pressures_1", "pressures_2"])
+            # the scan the reference lacks (fluid_count_nonfinite) finds exactly these cells
+            for img, arr in ((E.PRESSURES_1, s2.pressures_1), (E.PRESSURES_2, s2.pressures_2),
+                             (E.VELOCITIES_1, s2.velocities_1), (E.DIVERGENCES, s2.divergences)):
+                assert eng.count_nonfinite(img) == int(np.count_nonzero(~np.isfinite(arr)))
+            assert eng.count_nonfinite(E.PRESSURES_2) == 2
+            with pytest.raises(fluid_amd.FluidEngineError, match="fp32"):
+                eng.count_nonfinite(E.CELL_TYPES)
 
 
 @pytest.mark.parametrize("size,iters,steps,box", [((32, 32, 32), 20, 3, 0), ((24, 40, 20), 7, 2, 0),
@@ -203,6 +210,23 @@ def test_c1_config_64cubed_40_iterations():
         assert_state_equal(eng, st, ctx="C1: ")
     water = np.count_nonzero(st.cell_types == CELL_WATER)
     assert abs(cap / water - 8.0) < 1.5  # ~8 particles per water cell
+
+
+def test_c2_config_128cubed_80_iterations():
+    """BASELINE.json configs[1]: 128^3, 80 Jacobi iterations, the full 01a...14 pipeline on one GPU — two
+    whole steps of the dam break (8 particles per cell), every image and the particles bit-equal to the
+    oracle."""
+    p, cap = dam_break_params(128, 128, 128)
+    st = OracleState(p, cap, 80)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=80) as eng:
+        eng.run_init()
+        st.run_init()
+        for k in range(2):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"C2 step {k}: ")
+    water = np.count_nonzero(st.cell_types == CELL_WATER)
+    assert water > 50_000 and abs(cap / water - 8.0) < 1.5
 
 
 def test_step_by_sections_equals_run_step():
@@ -656,6 +680,36 @@ def test_full_step_quiet_bricks_match_oracle(quiet):
         assert eng.get_stat(E.STAT_QUIET_BRICKS) == 0
 
 
+@pytest.mark.parametrize("size", [(64, 33, 17), (260, 32, 16)])
+def test_lone_particles_in_wall_cells_are_cleared_every_step(size):
+    """A particle alone in a border cell: 02 makes the cell WATER, 03 makes it SOLID again, so its brick
+    never holds a water cell (with H = 33 / D = 17 the border planes y = 32 and z = 16 are bricks of their
+    own).  The reference clears the whole density image every step (fluid_flow_sections.h:163); the
+    engine's brick-wise 01a must clear these cells too — also after the particle has moved on (a steady
+    downward velocity carries one of them out of the wall into the open grid)."""
+    w, h, d = size
+    cap = 8
+    p = default_params(w, h, d, cap)
+    iters = 4
+    st = OracleState(p, cap, iters)
+    st.run_section("init_clear_velocities_1")
+    st.run_section("init_clear_cell_types")
+    st.velocities_1[..., 1] = -70.0          # 0.7 cells per step towards -y, everywhere
+    st.particles[:] = 0.0
+    st.particles[0] = (10.5, h - 0.1, 5.5, 1.0)     # ceiling cell, leaves it after two steps
+    st.particles[1] = (20.5, 10.5, d - 0.5, 1.0)    # +z wall
+    st.particles[2] = (0.5, 7.5, 3.5, 1.0)          # -x wall
+    st.particles[3] = (w - 0.5, h - 0.5, d - 0.5, 1.0)  # corner
+    with make_engine(st) as eng:
+        for k in range(6):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"wall droplets step {k}: ")
+        assert st.particle_densities.max() == 1      # never accumulates
+        assert st.particles[0, 1] < h - 1            # particle 0 has left the ceiling cell
+        assert eng.get_stat(E.STAT_QUIET_BRICKS) > 0  # the brick-wise path was the one running
+
+
 def _numpy_residual(st, pimg):
     """r = s + aii * P per WATER cell in fp32, pressure.comp:54-61 order (include/fluid_engine.h:
     fluid_pressure_residual)."""
@@ -741,6 +795,59 @@ def test_pressure_512cubed_default_equals_plain_and_window_matches_oracle():
     assert_bit_equal(keep[1][z0 + lo:z0 + hi], sw.pressures_2[lo:hi], "512^3 window P2")
 
 
+def c5_scene(shape, z_begin=0, global_depth=None, seed=5):
+    """Full-fluid scene at the C5 shape (walls SOLID, the rest WATER); the divergence comes from numpy's
+    generator (seeded per plane, so a slab sees the planes of the whole grid) instead of SplitMix64 to
+    keep half a billion cells cheap."""
+    d, h, w = shape
+    t = scenes.full_fluid_types(shape, z_begin, global_depth)
+    div = np.empty(shape, np.float32)
+    for z in range(d):
+        rng = np.random.default_rng([seed, z_begin + z])
+        div[z] = rng.random((h, w), dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+    return t, div
+
+
+def test_c5_shape_1024x1024x512_default_equals_plain_and_window_matches_oracle():
+    """BASELINE.json configs[4] on one GPU (25 GiB of attachments): 1024 x 1024 x 512 full-fluid grid,
+    6 sweeps.  W = 1024 is the four-x-tile instantiation of the two-sweeps-per-pass kernel.  The default
+    path agrees bit for bit with the one-thread-per-cell kernel on the images everywhere, and 20-plane
+    windows recomputed by the oracle (both domain faces and the middle) match outside their dependence
+    cones."""
+    w, h, d, iters = 1024, 1024, 512, 6
+    p = default_params(w, h, d, 0)
+    t, div = c5_scene((d, h, w))
+    keep = None
+    with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
+        eng.upload_image(E.CELL_TYPES, t)
+        eng.upload_image(E.DIVERGENCES, div)
+        for variant in (0, 1):
+            eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.run_section("12a_clear_pressures_1")
+            eng.run_section("12b_clear_pressures_2")
+            eng.solve_pressure(iters)
+            p1, p2 = eng.download_image(E.PRESSURES_1), eng.download_image(E.PRESSURES_2)
+            if keep is None:
+                keep = (p1, p2)
+            else:
+                assert_bit_equal(p1, keep[0], "C5 P1 default vs plain")
+                assert_bit_equal(p2, keep[1], "C5 P2 default vs plain")
+            del p1, p2
+    for z0 in (0, 246, d - 20):
+        zc = 20
+        pw = default_params(w, h, zc, 0)
+        sw = OracleState(pw, 0, iters)
+        sw.cell_types[...] = t[z0:z0 + zc]
+        sw.divergences[...] = div[z0:z0 + zc]
+        sw.pressures_1[...] = 1.0
+        sw.pressures_2[...] = 1.0
+        sw.solve_pressure(iters)
+        lo = 0 if z0 == 0 else iters
+        hi = zc if z0 + zc == d else zc - iters
+        assert_bit_equal(keep[0][z0 + lo:z0 + hi], sw.pressures_1[lo:hi], f"C5 window z0={z0} P1")
+        assert_bit_equal(keep[1][z0 + lo:z0 + hi], sw.pressures_2[lo:hi], f"C5 window z0={z0} P2")
+
+
 def test_full_step_256cubed_grouped_and_quiet_equal_the_section_list():
     """256^3 dam break (BASELINE config C3 shape), six whole steps: fluid_run_step with grouped passes,
     quiet bricks and box-shaped launches against the plain section list (one kernel per section, every
@@ -811,10 +918,14 @@ def test_advect_tiled_sampler_and_fallback(kernel, size, dt, scale):
 
 
 def test_checkpoint_round_trip(tmp_path):
-    """save_checkpoint / restore_checkpoint: a run resumed from the file continues bit-identically."""
+    """save_checkpoint / restore_checkpoint: a run resumed from the file continues bit-identically — the
+    file carries the run state too (a non-default iteration count and 09_diffuse mode here), and a path
+    without the .npz suffix names the same file on both sides."""
     p, cap = dam_break_params(32, 24, 16)
-    path = str(tmp_path / "state.npz")
+    p.diffuse_k = 0.8
+    path = str(tmp_path / "state")          # no suffix
     with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=9, surface_prep=True) as a:
+        a.set_diffuse_mode(E.DIFFUSE_INTENDED)
         a.run_init()
         for _ in range(3):
             a.run_step()
@@ -823,8 +934,12 @@ def test_checkpoint_round_trip(tmp_path):
             a.run_step()
         ref = {img: a.download_image(img) for img in list(E.IMAGE_DTYPES) + list(E.SURFACE_DTYPES)}
         ref_particles = a.download_particles()
-    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=9, surface_prep=True) as b:
+    import os
+    assert os.path.exists(path + ".npz") and not os.path.exists(path)
+    # the resuming context is created with other settings: the file's replace them
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=200, surface_prep=True) as b:
         b.restore_checkpoint(path)
+        assert b.pressure_iterations == 9 and b.diffuse_mode == E.DIFFUSE_INTENDED
         for _ in range(3):
             b.run_step()
         for img, exp in ref.items():
@@ -832,7 +947,10 @@ def test_checkpoint_round_trip(tmp_path):
         assert_bit_equal(b.download_particles(), ref_particles, "resumed particles")
     with fluid_amd.FluidEngine(p, particle_capacity=cap + 1) as c:
         with pytest.raises(fluid_amd.FluidEngineError, match="does not fit"):
-            c.restore_checkpoint(path)
+            c.restore_checkpoint(path + ".npz")
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, surface_prep=True, surface_diffuse_steps=6) as d:
+        with pytest.raises(fluid_amd.FluidEngineError, match="blur dispatches"):
+            d.restore_checkpoint(path)
 
 
 @pytest.mark.parametrize("size,omega,iters", [((24, 20, 16), 1.5, 5), ((17, 13, 9), 1.0, 3),

@@ -103,6 +103,8 @@ struct fluid_ctx {
     uint64_t early_offset = 0;    // one byte per brick: 255 = skipped by 02 / 03 / 04+05 of this step
     uint64_t pbricks_offset = 0;  // one byte per brick: a particle was counted there in this step
     bool early_in_use = false;    // inside fluid_run_step, between 01 and 06
+    bool early_wanted = false;    // the running 01 pass also derives the one-step test from its marks
+    bool pbricks_valid = false;   // pbricks() marks every brick in which the last 01 counted a particle
     bool quiet_valid = false;     // the streaks describe the images (nothing wrote them from outside)
     bool quiet_in_use = false;    // inside fluid_run_step, between 06 and 13: kernels may skip
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
@@ -748,7 +750,7 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
 // internal ids of the grouped passes, past the public section ids
 enum : int {
     STEP_0405_EXTRAPOLATE = FLUID_SECTION_COUNT + 1,
-    STEP_01A_CLEAR_WHERE_WATER_WAS,
+    STEP_01A_CLEAR_WHERE_PARTICLES_WERE,
     STEP_01_UPDATE_DENSITIES_MARK_BRICKS,
     STEP_0405_APPLY,
     STEP_0708_ADVECT_FORCES,
@@ -786,9 +788,10 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES:
             return fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
-        case STEP_01A_CLEAR_WHERE_WATER_WAS:  // quiet_bricks.h; bricks() still holds the previous step's map
-            hipLaunchKernelGGL(k_clear_density_where_water_was, cell4_grid(g), block, 0, c->stream, dens,
-                               g, c->bricks(), bk);
+        case STEP_01A_CLEAR_WHERE_PARTICLES_WERE:  // quiet_bricks.h; bricks() and pbricks() still hold the
+                                                   // previous step's water / particle maps
+            hipLaunchKernelGGL(k_clear_density_where_particles_were, cell4_grid(g), block, 0, c->stream,
+                               dens, g, c->bricks(), c->pbricks(), bk);
             break;
         case STEP_01_UPDATE_DENSITIES_MARK_BRICKS: {
             const int nb = (int)c->active_bytes;
@@ -800,11 +803,14 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
                                    c->particles(), c->particle_capacity, dens, g, pk, c->pbricks(), bk);
             }
-            hipLaunchKernelGGL(k_update_early_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
-                               c->bricks(), c->pbricks(), c->early(), bk);
+            c->pbricks_valid = true;
+            if (c->early_wanted)
+                hipLaunchKernelGGL(k_update_early_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
+                                   c->bricks(), c->pbricks(), c->early(), bk);
             break;
         }
         case FLUID_SEC_01_UPDATE_DENSITIES: {
+            c->pbricks_valid = false;  // counted without marking the bricks
             if (c->particle_capacity == 0) return FLUID_OK;
             const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
             const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
@@ -1682,18 +1688,28 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
     c->quiet_in_use = false;
     // the one-step test for the sections before 06 needs the previous step's water map in bricks():
     // nothing may have written the images since that step (quiet_valid still set)
-    const bool early = quiet && c->quiet_valid && c->mask_valid &&
+    const bool early = quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid &&
                        first == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES;
     c->early_in_use = false;
     for (int s = first; s < end;) {
         int rc, used = 1;
         if (early && s == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES) {
-            rc = timed_section(c, s, STEP_01A_CLEAR_WHERE_WATER_WAS);
+            rc = timed_section(c, s, STEP_01A_CLEAR_WHERE_PARTICLES_WERE);
+            c->early_wanted = true;
             if (rc == FLUID_OK)
                 rc = timed_section(c, FLUID_SEC_01_UPDATE_DENSITIES, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
+            c->early_wanted = false;
             if (rc) return rc;
             c->early_in_use = true;
             s += 2;
+            continue;
+        }
+        if (quiet && s == FLUID_SEC_01_UPDATE_DENSITIES) {
+            // not skipping yet (first step, or something wrote the images), but the next step's 01a clears
+            // only the bricks this pass marks
+            rc = timed_section(c, s, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
+            if (rc) return rc;
+            s += 1;
             continue;
         }
         if (s == FLUID_SEC_06_UPDATE_CELL_TYPES) c->early_in_use = false;
@@ -1879,6 +1895,34 @@ int fluid_pressure_residual(fluid_ctx* c, int image_id, float* max_abs, double* 
     if (max_abs) memcpy(max_abs, &host.max_bits, 4);
     if (sum_squares) *sum_squares = host.sum_sq;
     if (water_cells) *water_cells = host.cells;
+    return FLUID_OK;
+}
+
+int fluid_count_nonfinite(fluid_ctx* c, int image_id, uint64_t* count) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!count) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    int rc = check_image(c, image_id);
+    if (rc) return rc;
+    const bool is_float = image_id == FLUID_IMG_VELOCITIES_1 || image_id == FLUID_IMG_VELOCITIES_2 ||
+                          image_id == FLUID_IMG_PRESSURES_1 || image_id == FLUID_IMG_PRESSURES_2 ||
+                          image_id == FLUID_IMG_DIVERGENCES ||
+                          image_id == FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1 ||
+                          image_id == FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2;
+    if (!is_float) return c->fail(FLUID_ERR_INVALID_ARG, "image %d does not hold fp32 texels", image_id);
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* dev = reinterpret_cast<unsigned long long*>(c->flags() + 24);  // 8-byte aligned
+    HIP_TRY(c, hipMemsetAsync(dev, 0, 8, c->stream));
+    const int64_t words = (int64_t)(image_host_bytes(c, image_id) / 4);
+    if (words > 0) {
+        const int blocks = (int)std::min<int64_t>((words + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(k_count_nonfinite, dim3(blocks), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint32_t*>(image_host_base(c, image_id)), words, dev);
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned long long host = 0;
+    HIP_TRY(c, hipMemcpyAsync(&host, dev, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *count = host;
     return FLUID_OK;
 }
 

@@ -28,6 +28,20 @@ __global__ void k_fill_u8_tail(uint8_t* __restrict__ dst, int64_t begin, int64_t
     if (i < end) dst[i] = v;
 }
 
+// Diagnostics (fluid_count_nonfinite): number of fp32 words that are inf or NaN.  A water cell walled in
+// by SOLID on all six sides divides by aii = 0 (pressure.comp:62) and the result spreads through 13 into the
+// velocities; the reference never looks.  Grid-stride, one ballot + popcount per wavefront and step, one
+// atomic per wavefront.
+__global__ void k_count_nonfinite(const uint32_t* __restrict__ words, int64_t n,
+                                  unsigned long long* __restrict__ count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t mine = 0;
+    for (; i < n; i += stride) mine += (words[i] & 0x7F800000u) == 0x7F800000u ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63u) == 0u && mine != 0u) atomicAdd(count, (unsigned long long)mine);
+}
+
 // The pressure clears inside fluid_run_step: R32F fill that leaves quiet bricks alone (quiet_bricks.h),
 // four cells per thread, launched with cell4_grid() / cell_block().
 __global__ void k_fill_f32_unless_quiet(float* __restrict__ dst, float v, GridK g,

@@ -76,13 +76,17 @@ __global__ void k_update_early_quiet(const uint8_t* __restrict__ old_water,
     early[i] = any ? 0 : 255;
 }
 
-// 01a inside fluid_run_step: the density image is non-zero only where the previous step had water
-// (02: WATER <=> density > 0), so only those bricks are cleared.  cell4_grid() / cell_block().
-__global__ void k_clear_density_where_water_was(uint32_t* __restrict__ dens, GridK g,
-                                                const uint8_t* __restrict__ old_water, BrickK bk) {
-    if (old_water[brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X, (int)(blockIdx.y * 4u) / BRICK_Y,
-                              (int)blockIdx.z / BRICK_Z)] == 0)
-        return;
+// 01a inside fluid_run_step: the density image is non-zero only in the cells where the previous step's
+// 01 counted a particle, i.e. inside the bricks that pass marked (`old_particles`).  That is not the same
+// as "where the previous step had water": 02 turns a border cell with a particle into WATER, 03 then
+// into SOLID, so a lone droplet in a wall cell leaves a count in a brick without a water cell.  Both maps
+// are tested (the water map costs nothing and keeps the clear a superset).  cell4_grid() / cell_block().
+__global__ void k_clear_density_where_particles_were(uint32_t* __restrict__ dens, GridK g,
+                                                     const uint8_t* __restrict__ old_water,
+                                                     const uint8_t* __restrict__ old_particles, BrickK bk) {
+    const int b = brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X, (int)(blockIdx.y * 4u) / BRICK_Y,
+                              (int)blockIdx.z / BRICK_Z);
+    if ((old_water[b] | old_particles[b]) == 0) return;
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.W || y >= g.H) return;

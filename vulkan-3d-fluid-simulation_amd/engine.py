@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "fluid_pressure_loop_advance_part", "fluid_pressure_loop_edge_stream",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
-    "fluid_get_geometry", "fluid_set_option",
+    "fluid_get_geometry", "fluid_set_option", "fluid_count_nonfinite",
 ]
 
 
@@ -177,6 +177,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
+        "fluid_count_nonfinite": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -222,6 +223,11 @@ class FluidEngine:
             self._h = C.c_void_p()
             raise FluidEngineError(rc, msg.decode() if msg else "fluid_create failed")
         self.params = params.copy()
+        # run state the wrapper set (the C ABI has setters only): what a checkpoint records
+        self.pressure_iterations = int(pressure_iterations) if pressure_iterations else 200
+        self.diffuse_mode = DIFFUSE_REFERENCE_EXACT
+        self.solver, self.sor_omega = 0, 1.0
+        self.surface_diffuse_steps = int(surface_diffuse_steps) if surface_diffuse_steps else 4
         size = (C.c_uint32 * 3)()
         z0, zc, cap = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self._check(self._lib.fluid_get_geometry(self._h, C.byref(size), C.byref(z0), C.byref(zc),
@@ -307,29 +313,59 @@ class FluidEngine:
         return out
 
     # -- state I/O: everything a step reads, as one .npz -------------------------
+    CHECKPOINT_VERSION = 2
+
+    @staticmethod
+    def _checkpoint_path(path: str) -> str:
+        """numpy appends ".npz" to a name without it; use one spelling on both sides."""
+        path = os.fspath(path)
+        return path if path.endswith(".npz") else path + ".npz"
+
     def save_checkpoint(self, path: str):
-        """Images 0..7 (and the detailed-grid images of a surface_prep context), the particle buffer and
-        the parameter block.  Whole-grid contexts; a Z-slab run gathers per image (slab.SlabSimulation)."""
+        """Images 0..7 (and the detailed-grid images of a surface_prep context), the particle buffer, the
+        parameter block and the run state a resumed simulation needs for identical results (iteration
+        counts, 09_diffuse mode, solver).  Whole-grid contexts; a Z-slab run gathers per image
+        (slab.SlabSimulation).  `path` gets the suffix ".npz" if it lacks it."""
         data = {"params": np.frombuffer(self.params.to_bytes(), dtype=np.uint8),
                 "particles": self.download_particles(),
-                "meta": np.array([self.particle_capacity, 1 if self.surface_prep else 0], np.int64)}
+                "meta": np.array([self.particle_capacity, 1 if self.surface_prep else 0], np.int64),
+                "version": np.array([self.CHECKPOINT_VERSION], np.int64),
+                "run_state": np.array([self.pressure_iterations, self.diffuse_mode, self.solver,
+                                       self.surface_diffuse_steps], np.int64),
+                "sor_omega": np.array([self.sor_omega], np.float32)}
         for img in IMAGE_DTYPES:
             data[f"image_{img}"] = self.download_image(img)
         if self.surface_prep:
             for img in SURFACE_DTYPES:
                 data[f"image_{img}"] = self.download_image(img)
-        np.savez(path, **data)
+        with open(self._checkpoint_path(path), "wb") as f:
+            np.savez(f, **data)
 
     def restore_checkpoint(self, path: str):
         """Load a checkpoint written by save_checkpoint into this context (same grid, capacity and
-        parameter block sizes; the parameter values of the file replace the context's)."""
-        with np.load(path, allow_pickle=False) as z:
+        parameter block sizes).  The parameter values and the run state of the file replace the context's
+        (a version-1 file carries no run state: the context's stays).  The number of blur dispatches of a
+        surface_prep context is fixed at creation: a file written with another count is refused."""
+        with np.load(self._checkpoint_path(path), allow_pickle=False) as z:
+            version = int(z["version"][0]) if "version" in z.files else 1
+            if version > self.CHECKPOINT_VERSION:
+                raise FluidEngineError(ERR_INVALID_ARG, f"checkpoint format {version} is newer than "
+                                                        f"this build's ({self.CHECKPOINT_VERSION})")
             blob = z["params"].tobytes()
             if len(blob) != PARAMS_BYTES or int(z["meta"][0]) != self.particle_capacity:
                 raise FluidEngineError(ERR_SIZE_MISMATCH, "checkpoint does not fit this context")
             params = FluidParams.from_buffer_copy(blob)
             if tuple(params.size) != tuple(self.global_size):
                 raise FluidEngineError(ERR_SIZE_MISMATCH, "checkpoint grid differs from this context's")
+            if version >= 2:
+                iters, mode, solver, blur = (int(v) for v in z["run_state"])
+                if self.surface_prep and int(z["meta"][1]) and blur != self.surface_diffuse_steps:
+                    raise FluidEngineError(
+                        ERR_SIZE_MISMATCH, f"checkpoint was written with {blur} blur dispatches, this "
+                                           f"context runs {self.surface_diffuse_steps}")
+                self.set_pressure_iterations(iters)
+                self.set_diffuse_mode(mode)
+                self.set_pressure_solver(solver, float(z["sor_omega"][0]))
             self.set_params(params)
             for img in IMAGE_DTYPES:
                 self.upload_image(img, z[f"image_{img}"])
@@ -380,6 +416,7 @@ class FluidEngine:
     def set_pressure_solver(self, solver: int, omega: float = 1.0):
         """Opt-in red-black SOR for the pressure system (include/fluid_engine.h; not the reference's)."""
         self._check(self._lib.fluid_set_pressure_solver(self._h, solver, omega))
+        self.solver, self.sor_omega = int(solver), float(omega)
 
     def run_surface_diffuse_dispatch(self, is_even_iteration: int):
         self._check(self._lib.fluid_run_surface_diffuse_dispatch(self._h, is_even_iteration))
@@ -411,9 +448,11 @@ class FluidEngine:
 
     def set_pressure_iterations(self, iterations: int):
         self._check(self._lib.fluid_set_pressure_iterations(self._h, iterations))
+        self.pressure_iterations = int(iterations)
 
     def set_diffuse_mode(self, mode: int):
         self._check(self._lib.fluid_set_diffuse_mode(self._h, mode))
+        self.diffuse_mode = int(mode)
 
     def set_option(self, option: int, value: int):
         self._check(self._lib.fluid_set_option(self._h, option, value))
@@ -513,6 +552,12 @@ class FluidEngine:
         self._check(self._lib.fluid_pressure_residual(self._h, image_id, C.byref(m), C.byref(s),
                                                       C.byref(n)))
         return float(m.value), float(s.value), int(n.value)
+
+    def count_nonfinite(self, image_id: int) -> int:
+        """inf / NaN words in the owned planes of a float image (include/fluid_engine.h)."""
+        v = C.c_uint64(0)
+        self._check(self._lib.fluid_count_nonfinite(self._h, image_id, C.byref(v)))
+        return int(v.value)
 
     def get_stat(self, stat: int) -> int:
         v = C.c_uint64(0)
