@@ -411,6 +411,31 @@ int fluid_slab_status(fluid_ctx* ctx, uint32_t* halo_violation);
 int fluid_particles_collect_leavers(fluid_ctx* ctx, void** device_list, uint32_t* count);
 int fluid_particles_adopt(fluid_ctx* ctx, const void* device_list, uint32_t count);
 
+/* The velocity sampler of 07_advect on a Z slab (particles and back-traces are never
+ * clamped, advect.comp:63-78).  A back-trace reaches floor(|v.z| * dt) + 2 planes from its cell, so how
+ * many ghost planes of VELOCITIES_1 07 needs depends on the flow.  The protocol the slab driver
+ * (fluid_slab.h) follows, every step:
+ *   1. exchange `n` ghost planes of VELOCITIES_1 after 05 (n = fluid_set_sampler_halo, 1..
+ *      FLUID_IMAGE_GHOST_PLANES; the kernels treat planes beyond n as unknown) and run 07 (or 07+08);
+ *   2. read fluid_slab_status and combine it over all ranks with MAX.  0: done.
+ *   3. otherwise the pass is redone (07 reads VELOCITIES_1 and CELL_TYPES, writes VELOCITIES_2: nothing
+ *      it read has changed): all-reduce(MAX) fluid_sampler_reach; if it fits the image's ghost planes,
+ *      exchange that many and run the section again; if not, fluid_sampler_wide_begin(reach, reach)
+ *      allocates a source with that many planes per side (clipped to the grid) holding this slab's
+ *      planes, the caller fills the others from the ranks that own them (fluid_sampler_wide_plane_ptr),
+ *      and fluid_run_advect_wide runs the pass on it.  Either way the flag is clear afterwards: the step
+ *      never fails because the fluid is fast.
+ * 14_particles samples at the position of a particle this slab owns: one ghost plane always suffices. */
+int fluid_set_sampler_halo(fluid_ctx* ctx, uint32_t planes);
+/* Upper bound of the planes a back-trace of 07 can reach beyond its cell, from max |VELOCITIES_1.z| over
+ * the owned planes (wave64 shuffle reduction, one atomic per wavefront); fluid_size.z if a velocity is not
+ * finite.  Synchronises the stream. */
+int fluid_sampler_reach(fluid_ctx* ctx, uint32_t* planes);
+int fluid_sampler_wide_begin(fluid_ctx* ctx, uint32_t planes_below, uint32_t planes_above);
+/* plane: local index, -below' .. z_count + above' - 1 (the counts clipped to the grid) */
+int fluid_sampler_wide_plane_ptr(fluid_ctx* ctx, int32_t plane, void** device_ptr, uint64_t* bytes);
+int fluid_run_advect_wide(fluid_ctx* ctx, int with_forces);
+
 /* Geometry of this context. */
 int fluid_get_geometry(const fluid_ctx* ctx, uint32_t global_size[3], uint32_t* slab_z_begin,
                        uint32_t* slab_z_count, uint64_t* particle_capacity);

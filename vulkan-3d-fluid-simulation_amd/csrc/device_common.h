@@ -33,6 +33,11 @@ struct GridK {
     int Dg;         // global depth
     int z0;         // global z of local plane 0
     int64_t plane;  // W*H cells
+    // Velocity sampler (07_advect, 14_particles) on a Z slab: planes below local plane 0 / above plane
+    // Dl-1 of the image being sampled that hold current data of the neighbouring slabs.  A tap beyond
+    // them raises the context's halo-violation flag.  IMG_GHOST at most for VELOCITIES_1 itself; the wide
+    // source of the fallback pass (fluid_sampler_wide_begin) has as many as the back-traces need.
+    int sg_lo, sg_hi;
 };
 
 // Hot-path fields of the 264-byte params block (include/fluid_engine.h: fluid_params), passed by

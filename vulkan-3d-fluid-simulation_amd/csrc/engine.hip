@@ -115,6 +115,11 @@ struct fluid_ctx {
     bool v1_w_zero = false;               // every texel of VELOCITIES_1 has w == +0.0f (kernels_step_fused.h)
     bool box_pending = false;             // that copy has been enqueued and not been waited for
     ActiveBox box;                        // where the water is, for launch shaping
+    // wide sampler source of the 07 fallback pass (fluid_sampler_wide_begin): wide_lo + Dl + wide_hi planes
+    // of RGBA32F, allocated on first use outside the arena
+    float4* wide = nullptr;
+    uint64_t wide_bytes = 0;
+    int wide_lo = 0, wide_hi = 0;
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
     uint32_t leavers_capacity = 0;
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
@@ -1169,6 +1174,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->g.Dl = (int)dl;
     c->g.z0 = (int)z0;
     c->g.plane = (int64_t)p.fluid_size[0] * p.fluid_size[1];
+    c->g.sg_lo = c->g.sg_hi = IMG_GHOST;
     c->is_slab = dl != p.fluid_size[2];
     c->particle_capacity = capacity;
     c->surface = L.surf_cells != 0;
@@ -1260,6 +1266,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->ev_pass_start) (void)hipEventDestroy(c->ev_pass_start);
     if (c->ev_edges_done) (void)hipEventDestroy(c->ev_edges_done);
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
+    if (c->wide) (void)hipFree(c->wide);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1958,6 +1965,109 @@ int fluid_slab_status(fluid_ctx* c, uint32_t* halo_violation) {
     *halo_violation = v;
     if (v) HIP_TRY(c, hipMemsetAsync(c->flags(), 0, 4, c->stream));
     return FLUID_OK;
+}
+
+// ---- the velocity sampler on Z slabs: how many ghost planes are current, and the fallback when the
+// ---- fluid moves further than that in one step ------------------------------------------
+int fluid_set_sampler_halo(fluid_ctx* c, uint32_t planes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (planes < 1 || planes > (uint32_t)IMG_GHOST)
+        return c->fail(FLUID_ERR_INVALID_ARG, "sampler halo of %u planes: 1..%d", planes, IMG_GHOST);
+    c->g.sg_lo = c->g.sg_hi = (int)planes;
+    return FLUID_OK;
+}
+
+int fluid_sampler_reach(fluid_ctx* c, uint32_t* planes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!planes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t* dev = c->flags() + 26;
+    HIP_TRY(c, hipMemsetAsync(dev, 0, 4, c->stream));
+    const int64_t cells = (int64_t)c->owned_cells();
+    if (cells > 0) {
+        const int blocks = (int)std::min<int64_t>((cells + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(k_max_abs_vz, dim3(blocks), dim3(256), 0, c->stream,
+                           c->plane0<float4>(FLUID_IMG_VELOCITIES_1), cells, dev);
+        HIP_TRY(c, hipGetLastError());
+    }
+    uint32_t bits = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bits, dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float vmax;
+    memcpy(&vmax, &bits, 4);
+    // advect.comp:75-77: the back-traced point lies |v.z * dt| from the face position, v.z a trilinear
+    // blend of texels (each |.| <= vmax, up to rounding: the factor), and its two z taps are the planes
+    // around it: floor(|v.z| * dt) + 2 planes from the cell's own; one more for the roundings.
+    const double reach = (double)vmax * (double)fabsf(c->pk.dt) * (1.0 + 1e-5);
+    uint32_t n = (uint32_t)c->g.Dg;
+    if (vmax == vmax && reach < (double)c->g.Dg) n = std::min<uint32_t>((uint32_t)reach + 3u, n);
+    *planes = n;
+    return FLUID_OK;
+}
+
+int fluid_sampler_wide_begin(fluid_ctx* c, uint32_t below, uint32_t above) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // planes that exist in the grid: the sampler clamps its taps to [0, Dg)
+    const uint32_t lo = std::min<uint32_t>(below, (uint32_t)c->g.z0);
+    const uint32_t hi = std::min<uint32_t>(above, (uint32_t)(c->g.Dg - c->g.z0 - c->g.Dl));
+    const uint64_t bytes = (uint64_t)(lo + (uint32_t)c->g.Dl + hi) * (uint64_t)c->g.plane * 16u;
+    if (bytes > c->wide_bytes) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->wide) (void)hipFree(c->wide);
+        c->wide = nullptr;
+        c->wide_bytes = 0;
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, bytes) != hipSuccess)
+            return c->fail(FLUID_ERR_OUT_OF_MEMORY, "wide sampler source of %llu bytes",
+                           (unsigned long long)bytes);
+        c->wide = static_cast<float4*>(ptr);
+        c->wide_bytes = bytes;
+    }
+    c->wide_lo = (int)lo;
+    c->wide_hi = (int)hi;
+    HIP_TRY(c, hipMemcpyAsync(c->wide + (uint64_t)lo * c->g.plane, c->plane0<float4>(FLUID_IMG_VELOCITIES_1),
+                              c->owned_cells() * 16u, hipMemcpyDeviceToDevice, c->stream));
+    return FLUID_OK;
+}
+
+int fluid_sampler_wide_plane_ptr(fluid_ctx* c, int32_t plane, void** device_ptr, uint64_t* bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (!c->wide) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_sampler_wide_begin first");
+    if (plane < -c->wide_lo || plane >= c->g.Dl + c->wide_hi)
+        return c->fail(FLUID_ERR_INVALID_ARG, "plane %d outside [%d, %d)", plane, -c->wide_lo,
+                       c->g.Dl + c->wide_hi);
+    *bytes = (uint64_t)c->g.plane * 16u;
+    *device_ptr = c->wide + (uint64_t)(plane + c->wide_lo) * c->g.plane;
+    return FLUID_OK;
+}
+
+int fluid_run_advect_wide(fluid_ctx* c, int with_forces) {
+    if (c) c->quiet_valid = false;
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->wide) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_sampler_wide_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    SectionTimer tm{c};
+    int rc = tm.begin(FLUID_SEC_07_ADVECT);
+    if (rc) return rc;
+    GridK g = c->g;
+    g.sg_lo = c->wide_lo;
+    g.sg_hi = c->wide_hi;
+    const float4* src = c->wide + (uint64_t)c->wide_lo * c->g.plane;  // owned plane 0 of the wide source
+    BrickK bk;
+    k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
+    HIP_TRY(c, hipMemsetAsync(c->flags(), 0, 4, c->stream));  // the pass that raised it is being redone
+    const uint8_t* T = c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES);
+    float4* V2 = c->plane0<float4>(FLUID_IMG_VELOCITIES_2);
+    if (with_forces)
+        hipLaunchKernelGGL(k07_advect<true>, cell_grid(g), cell_block(), 0, c->stream, T, src, V2, g, c->pk,
+                           c->flags(), (const uint8_t*)nullptr, bk, 1);
+    else
+        hipLaunchKernelGGL(k07_advect<false>, cell_grid(g), cell_block(), 0, c->stream, T, src, V2, g,
+                           c->pk, c->flags(), (const uint8_t*)nullptr, bk, 1);
+    HIP_TRY(c, hipGetLastError());
+    return tm.end();
 }
 
 int fluid_particles_collect_leavers(fluid_ctx* c, void** device_list, uint32_t* count) {

@@ -97,9 +97,10 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
     axis_taps(pz + mz, axes.z, z0, z1, az);
     z0 -= g.z0;
     z1 -= g.z0;
-    {   // Z-slab contexts hold IMG_GHOST planes of the neighbouring slabs: a tap beyond them cannot be
-        // served (never happens on a whole-grid context, whose taps are clamped into the grid above)
-        const int lo = -IMG_GHOST, hi = g.Dl + IMG_GHOST - 1;
+    {   // Z-slab contexts hold sg_lo / sg_hi current planes of the neighbouring slabs: a tap beyond them
+        // cannot be served (never happens on a whole-grid context, whose taps are clamped into the grid
+        // above)
+        const int lo = -g.sg_lo, hi = g.Dl + g.sg_hi - 1;
         if (z0 < lo || z1 > hi) {
             *violation = 1u;
             z0 = min(max(z0, lo), hi);
@@ -226,7 +227,7 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
     const int gz = g.z0 + lz;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // planes of the image that exist for this context (ghost planes of a slab; the grid itself otherwise)
-    const int zlo = max(-IMG_GHOST, -g.z0), zhi = min(g.Dl + IMG_GHOST - 1, g.Dg - 1 - g.z0);
+    const int zlo = max(-g.sg_lo, -g.z0), zhi = min(g.Dl + g.sg_hi - 1, g.Dg - 1 - g.z0);
     for (int xc = 0; xc < xchunks; xc++) {
         const int xb = ((int)blockIdx.x * xchunks + xc) * 64;  // first cell of this chunk
         if (xb >= g.W) break;                                  // uniform
@@ -279,6 +280,19 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
             v2[id] = o;  // :96
         }
     }
+}
+
+// How far 07_advect's back-traces can reach along z (fluid_sampler_reach): max |VELOCITIES_1.z| over the
+// owned cells as a bit pattern — for non-negative floats the unsigned order of the bits is the order of
+// the values, and a NaN sorts above +inf, so one atomicMax per wavefront keeps "some value is not finite"
+// too.  Reduced per wavefront with wave64 shuffles.
+__global__ void k_max_abs_vz(const float4* __restrict__ v1, int64_t cells, uint32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t m = 0u;
+    for (; i < cells; i += stride) m = max(m, __float_as_uint(v1[i].z) & 0x7FFFFFFFu);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
+    if ((threadIdx.x & 63u) == 0u && m != 0u) atomicMax(out, m);
 }
 
 // 14_particles/particles.comp:45-51

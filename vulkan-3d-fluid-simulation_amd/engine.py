@@ -84,6 +84,8 @@ EXPORTED_SYMBOLS = [
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
     "fluid_get_geometry", "fluid_set_option", "fluid_count_nonfinite",
+    "fluid_set_sampler_halo", "fluid_sampler_reach", "fluid_sampler_wide_begin",
+    "fluid_sampler_wide_plane_ptr", "fluid_run_advect_wide",
 ]
 
 
@@ -178,6 +180,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
         "fluid_count_nonfinite": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
+        "fluid_set_sampler_halo": (C.c_int, [vp, u32]),
+        "fluid_sampler_reach": (C.c_int, [vp, C.POINTER(u32)]),
+        "fluid_sampler_wide_begin": (C.c_int, [vp, u32, u32]),
+        "fluid_sampler_wide_plane_ptr": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(u64)]),
+        "fluid_run_advect_wide": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
