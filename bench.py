@@ -8,8 +8,10 @@ reference's loop section `12_solve_pressure x iters` (fluid_flow_sections.h:300-
 the two pressure clears (:298-299), on the "full-fluid" synthetic grid of SURVEY.md §8d (faces
 SOLID, interior WATER, divergence ~ U(-1,1) from SplitMix64 seed 0x5EED0012): K steps are timed
 between barriers, value = K*iters / wall time.  Inputs are resident in HBM before the timed region.
-With N > 1 the grid is split into Z slabs, one process per GPU, one-plane halo exchange per sweep over
-RCCL (torch.distributed "nccl"); the total grid is fixed (strong scaling).
+With N > 1 the grid is split into Z slabs, one process per GPU, driven by the C++ slab driver
+(include/fluid_slab.h): h ghost planes every h sweeps by ncclSend / ncclRecv between Z-neighbours
+(torch.distributed only carries the communicator's unique id and the barriers around the timed
+region); the total grid is fixed (strong scaling).
 
 The same JSON line also carries
   roofline     : the Jacobi kernel's algorithmic bytes (13 B/cell/sweep) / its average launch
@@ -275,31 +277,38 @@ def surface_prep_bench(n, iters, device):
 
 
 def slab_full_step_bench(size, iters, steps, dist_ctx, overlap=None):
-    """Full simulation steps/sec on Z slabs (slab.SlabSimulation), dam-break scene."""
+    """Full simulation steps/sec on Z slabs (the C++ driver of include/fluid_slab.h), dam-break scene."""
     import torch.distributed as dist
 
     import fluid_amd
-    from fluid_amd.slab import SlabSimulation
+    from fluid_amd import slab as S
 
     p, cap = fluid_amd.dam_break_params(*size)
-    sim = SlabSimulation(p, cap, iters, dist_ctx, overlap=overlap)
+    sim = S.SlabDriver(p, dist_ctx.rank, dist_ctx.world, particle_capacity=cap, pressure_iterations=iters,
+                       device=dist_ctx.device.index if dist_ctx.device.index is not None else -1,
+                       overlap=overlap)
+    if dist_ctx.world > 1:
+        sim.attach_rccl()
     sim.run_init()
     for _ in range(2):
         sim.run_step()
     steps = min(steps, 5)
-    sim.compute.sync()
+    sim.engine.sync()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         sim.run_step()
-    sim.compute.sync()
+    sim.engine.sync()
     dist.barrier()
     dt = time.perf_counter() - t0
+    out = {"workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi "
+                       f"iters, Z slabs over {dist_ctx.world} GPUs",
+           "steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "particles_migrated_by_rank0": sim.stat(S.STAT_MIGRATED),
+           "sampler_halo_planes": sim.stat(S.STAT_SAMPLER_HALO),
+           "advect_passes_redone": sim.stat(S.STAT_SAMPLER_RERUNS)}
     sim.close()
-    return {"workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi "
-                        f"iters, Z slabs over {dist_ctx.world} GPUs",
-            "steps_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "particles_migrated": sim.migrated}
+    return out
 
 
 def main():
@@ -324,12 +333,14 @@ def main():
         fluid_amd.build_engine()
 
     if world > 1 or os.environ.get("FLUID_BENCH_FORCE_SLAB") == "1":  # (the env var: tests only)
-        from fluid_amd.slab import SlabPressureSolver, init_distributed
-        dist_ctx = init_distributed(local_rank)
-        solver = SlabPressureSolver.create_gpu(size, args.iters, dist_ctx,
-                                               pressure_kernel=args.pressure_kernel)
+        from fluid_amd import slab as S
+        dist_ctx = S.init_distributed(local_rank)
+        solver = S.SlabDriver.create_full_fluid(size, args.iters, dist_ctx)
+        solver.engine.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
         result = solver.benchmark(args.steps, args.warmup)
-        halo = solver.effective_halo()
+        halo = solver.stat(S.STAT_EFFECTIVE_HALO)
+        result["exchanges_per_step"] = solver.stat(S.STAT_EXCHANGES) // max(
+            args.steps + args.warmup + (6 if result["halo_overlap"].get("probed") else 0), 1)
         solver.close()
         full = None
         if not args.no_full_step:

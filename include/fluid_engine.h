@@ -342,6 +342,9 @@ int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** de
  * fluid_run_pressure_dispatch and exchange one plane of the written image per sweep instead). */
 #define FLUID_LOOP_MAX_HALO 8
 int fluid_pressure_loop_begin(fluid_ctx* ctx);
+/* 1 if the explicit loop can run on this context (fluid_size.x % 4 == 0 and the pressure kernel option
+ * allows the working-buffer path), 0 if the caller has to loop over fluid_run_pressure_dispatch. */
+int fluid_pressure_loop_available(fluid_ctx* ctx);
 int fluid_pressure_loop_max_sweeps(fluid_ctx* ctx);
 int fluid_pressure_loop_advance(fluid_ctx* ctx, uint32_t sweeps, int keep_intermediate,
                                 int* written_buffer);
@@ -396,23 +399,41 @@ int fluid_notify_ghost_planes_written(fluid_ctx* ctx, int image_id);
  * With the grouped passes (fluid_run_section_group): 04+05 in place of 04, 05; 07+08 in place of 07,
  * 08; and, instead of the one-plane VELOCITIES_1 exchange after 10, one plane of VELOCITIES_2 after 08
  * followed by 09+10+11.
- * 06 copies one ghost plane per side along with the owned planes.  The velocity sampler of 07 / 14
- * can reach as far as the fluid moves in one step; a tap beyond the ghost planes raises the halo
- * violation flag (fluid_slab_status reads and clears it): results of that step are then not exact.
+ * 06 copies one ghost plane per side along with the owned planes.  The velocity sampler of 07 can
+ * reach as far as the fluid moves in one step; a tap beyond the current ghost planes raises the halo
+ * violation flag (fluid_slab_status reads and clears it) and the pass is redone with more of them
+ * (fluid_sampler_* below).  include/fluid_slab.h drives all of this.
  *
  * Particles: every rank holds the full-capacity buffer; global particle i lives in slot i of the rank
  * whose slab contains the plane the particle counts towards (01_update_densities), the other ranks
  * hold a tombstone there (w = bit pattern 0x7FC0DEAD).  fluid_upload_buffer(PARTICLES_BUF) takes the
- * global array and keeps the owned slots.  After 14: collect_leavers lists (device memory, 32-byte
- * entries {float4 data; uint32 index; 3 x pad}) the particles that left this slab and buries them; the
- * caller all-gathers the lists and every rank adopts the entries that are now its own. */
+ * global array and keeps the owned slots.  After 14 the particles that left the slab are handed to the
+ * Z-neighbours (fluid_particles_* below). */
 #define FLUID_IMAGE_GHOST_PLANES 4
 int fluid_slab_status(fluid_ctx* ctx, uint32_t* halo_violation);
-int fluid_particles_collect_leavers(fluid_ctx* ctx, void** device_list, uint32_t* count);
-int fluid_particles_adopt(fluid_ctx* ctx, const void* device_list, uint32_t count);
+
+/* Particle hand-over between Z-neighbours.  Four lists of 32-byte entries {float4 data; uint32 index;
+ * 3 x pad} in device memory: FLUID_MIGRATE_SEND_DOWN / _UP hold what this slab passes to the neighbour
+ * below (towards z = 0) / above, FLUID_MIGRATE_FROM_BELOW / _ABOVE are where the caller's Recv puts what
+ * those neighbours pass.  One round:
+ *   collect(reset, counts, left)   lists the particles this slab holds but does not own (appending to the
+ *       send lists, after clearing them if `reset`) and buries their slots; counts[] = entries now in the
+ *       down / up list; *left = particles that found their list full and stayed — another round is needed
+ *   the caller sends counts[d] entries of list d to that neighbour and receives the neighbours' entries
+ *   adopt_received(nb, na, fwd)    clears the send lists, adopts the received entries this slab owns and
+ *       appends the others to the send list of the direction they were travelling in (a particle that
+ *       crossed more than one slab in a step); fwd[] = entries now in the down / up list.
+ * The hand-over is complete when, over all ranks, nothing was sent and nothing is left.  Every call
+ * synchronises the stream (the counts are host values). */
+enum { FLUID_MIGRATE_SEND_DOWN = 0, FLUID_MIGRATE_SEND_UP = 1, FLUID_MIGRATE_FROM_BELOW = 2,
+       FLUID_MIGRATE_FROM_ABOVE = 3 };
+int fluid_particles_migrate_list(fluid_ctx* ctx, int which, void** device_list, uint32_t* capacity_entries);
+int fluid_particles_collect(fluid_ctx* ctx, int reset_lists, uint32_t counts[2], uint32_t* left_behind);
+int fluid_particles_adopt_received(fluid_ctx* ctx, uint32_t from_below, uint32_t from_above,
+                                   uint32_t forwarded[2]);
 
 /* The velocity sampler of 07_advect on a Z slab (particles and back-traces are never
- * clamped, advect.comp:63-78).  A back-trace reaches floor(|v.z| * dt) + 2 planes from its cell, so how
+ * clamped, advect.comp:63-78).  A back-trace reaches floor(|v.z| * dt) + 1 planes from its cell, so how
  * many ghost planes of VELOCITIES_1 07 needs depends on the flow.  The protocol the slab driver
  * (fluid_slab.h) follows, every step:
  *   1. exchange `n` ghost planes of VELOCITIES_1 after 05 (n = fluid_set_sampler_halo, 1..

@@ -14,8 +14,8 @@ from fluid_amd.params import LAYOUT_OFFSETS, PARAMS_BYTES, FluidParams, default_
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "fluid_engine.h")).read()
+def header_functions(header="fluid_engine.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fluid_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,6 +28,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fluid_engine.h but not exported"
     assert sorted(E.EXPORTED_SYMBOLS) == declared
     assert lib.fluid_abi_version() == 1
+
+
+def test_library_exports_every_symbol_of_the_slab_driver_header():
+    """include/fluid_slab.h (the multi-GPU driver) lives in the same library; its host-only entry points
+    work without a GPU, and creating an engine-backed driver without one fails loudly."""
+    from fluid_amd import slab as S
+
+    lib = S._lib()
+    declared = header_functions("fluid_slab.h")
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fluid_slab.h but not exported"
+    assert sorted(S.EXPORTED_SYMBOLS) == declared
+    assert S.partition_z(512, 8) == [(64 * r, 64) for r in range(8)]
+    assert S.partition_z(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    if not os.path.exists("/dev/kfd"):
+        with pytest.raises(S.SlabError) as e:
+            S.SlabDriver(default_params(16, 16, 16, 0), 0, 2)
+        assert e.value.code in (E.ERR_NO_DEVICE, E.ERR_HIP)
+    with pytest.raises(S.SlabError, match="cannot give rank"):
+        S.SlabDriver(default_params(16, 16, 4, 0), 5, 8)
 
 
 def test_params_struct_matches_reference_layout_file():

@@ -1,8 +1,8 @@
-"""The GPU slab path (GpuSlabCompute: torch-owned arena, engine on torch's stream, plane views,
-slab kernels with real neighbour data in the ghost planes) rehearsed with 2 ranks on the ONE GPU
-of the test box.  RCCL refuses two ranks on one device, so the planes travel over gloo through
-host staging (transport="staged"); the schedule and every device-side piece are the product's.
-Result must equal the single-domain oracle bit for bit."""
+"""The GPU slab path (the C++ driver of include/fluid_slab.h on Z-slab engine contexts with real
+neighbour data in the ghost planes) rehearsed with 2 and 3 ranks on the ONE GPU of the test box.  RCCL
+refuses two ranks on one device, so the planes travel over gloo through host staging (the driver's
+callback transport); the schedule and every device-side piece are the product's.  Result must equal
+the single-domain oracle bit for bit."""
 import os
 import socket
 import sys
@@ -23,70 +23,65 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir, edge=False):
+def _worker(rank, world, port, size, iters, seed, variant, halo, out_dir, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    import torch
     import torch.distributed as dist
 
     import fluid_amd  # noqa: F401
     from fluid_amd import engine as E
-    from fluid_amd.slab import (DistContext, GpuSlabCompute, SlabPressureSolver, partition_z)
+    from fluid_amd import slab as S
     from helpers import random_state
 
     dist.init_process_group(backend="gloo")
-    torch.cuda.set_device(0)
-    ctx = DistContext(rank, world, torch.device("cuda", 0), "gloo")
     w, h, d = size
     st = random_state(size, seed=seed, iters=iters)
-    slab = partition_z(d, world)[rank]
-    comp = GpuSlabCompute(st.params, slab, ctx.device, pressure_kernel=variant, edge_stream=edge is True)
-    solver = SlabPressureSolver(size, iters, ctx, comp, slab, transport="staged", halo_depth=halo)
-    if edge == "before":   # only the pass before an exchange is split
-        solver.overlap = "before"
-    z0, n = slab
-    comp.upload(E.CELL_TYPES, st.cell_types[z0:z0 + n])
-    comp.upload(E.DIVERGENCES, st.divergences[z0:z0 + n])
-    solver.exchange(E.CELL_TYPES)
-    solver.step()
-    a1, a2 = solver.gather_pressures()
-    comp.upload(E.PRESSURES_1, st.pressures_1[z0:z0 + n])
-    comp.upload(E.PRESSURES_2, st.pressures_2[z0:z0 + n])
-    solver.solve(iters + 1)
-    b1, b2 = solver.gather_pressures()
+    drv = S.SlabDriver(st.params, rank, world, pressure_iterations=iters, device=0, halo_depth=halo,
+                       overlap=overlap)
+    drv.attach_torch_transport(device_memory=True)
+    drv.engine.set_option(E.OPT_PRESSURE_KERNEL, variant)
+    z0, n = drv.slab
+    drv.upload_image(E.CELL_TYPES, st.cell_types[z0:z0 + n])
+    drv.engine.upload_image(E.DIVERGENCES, st.divergences[z0:z0 + n])
+    drv.pressure_step()
+    a1, a2 = drv.gather_image(E.PRESSURES_1), drv.gather_image(E.PRESSURES_2)
+    drv.engine.upload_image(E.PRESSURES_1, st.pressures_1[z0:z0 + n])
+    drv.engine.upload_image(E.PRESSURES_2, st.pressures_2[z0:z0 + n])
+    drv.solve(iters + 1)
+    b1, b2 = drv.gather_image(E.PRESSURES_1), drv.gather_image(E.PRESSURES_2)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "result.npz"), a1=a1, a2=a2, b1=b1, b2=b2)
+        np.savez(os.path.join(out_dir, "result.npz"), a1=a1, a2=a2, b1=b1, b2=b2,
+                 overlapped=drv.stat(S.STAT_OVERLAPPED))
     dist.barrier()
-    solver.close()
+    drv.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,iters,variant,halo,edge", [
-    (2, (64, 24, 20), 6, 0, 2, False),     # working-buffer loop, two sweeps per exchange
-    (2, (64, 24, 20), 21, 0, 8, False),    # eight sweeps per exchange (redundant ghost-region compute), odd tail
-    (2, (64, 24, 40), 12, 0, 6, False),    # six
-    (3, (260, 9, 11), 5, 0, 8, False),     # slabs of 4/4/3 planes clip the halo to 2
-    (3, (256, 12, 13), 8, 7, 4, False),    # explicit fast-path kernel option
-    (2, (64, 24, 20), 7, 2, 8, False),     # general kernel on the images: one plane per sweep
-    (2, (17, 9, 8), 4, 0, 8, False),       # width not a multiple of 4: falls back to the images as well
-    (2, (64, 24, 40), 21, 0, 8, False),    # slabs of 20 planes, halo 8: split passes around the exchanges
-    (3, (256, 12, 30), 14, 0, 4, False),   # three ranks, halo 4 on slabs of 10 planes, split passes
-    (2, (512, 7, 24), 12, 0, 4, False),    # two x tiles per row
-    (2, (64, 24, 40), 21, 0, 8, True),    # the same with the EDGES launches on the second engine stream
-    (3, (256, 12, 30), 14, 0, 4, True),
-    (2, (64, 24, 40), 21, 0, 8, "before"),  # half-overlapped schedule
+@pytest.mark.parametrize("world,size,iters,variant,halo,overlap", [
+    (2, (64, 24, 20), 6, 0, 2, 2),     # working-buffer loop, two sweeps per exchange
+    (2, (64, 24, 20), 21, 0, 8, 2),    # eight sweeps per exchange (redundant ghost-region compute), odd tail
+    (2, (64, 24, 40), 12, 0, 6, 2),    # six
+    (3, (260, 9, 11), 5, 0, 8, 2),     # slabs of 4/4/3 planes clip the halo to 2
+    (3, (256, 12, 13), 8, 7, 4, 2),    # explicit fast-path kernel option
+    (2, (64, 24, 20), 7, 2, 8, 2),     # general kernel on the images: one plane per sweep
+    (2, (17, 9, 8), 4, 0, 8, 2),       # width not a multiple of 4: falls back to the images as well
+    (2, (64, 24, 40), 21, 0, 8, 2),    # slabs of 20 planes, halo 8: split passes around the exchanges
+    (3, (256, 12, 30), 14, 0, 4, 2),   # three ranks, halo 4 on slabs of 10 planes, split passes
+    (2, (512, 7, 24), 12, 0, 4, 2),    # two x tiles per row
+    (2, (64, 24, 40), 21, 0, 8, 1),    # half-overlapped schedule: only the pass before an exchange is split
+    (3, (256, 12, 30), 14, 0, 4, 0),   # exchanges in line
 ])
-def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, edge, tmp_path):
+def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant, halo, overlap, tmp_path):
     import torch.multiprocessing as mp
 
     from helpers import assert_bit_equal, random_state
 
     seed = 33
     mp.start_processes(_worker, args=(world, _free_port(), size, iters, seed, variant, halo,
-                                      str(tmp_path), edge),
+                                      str(tmp_path), overlap),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     st = random_state(size, seed=seed, iters=iters)
@@ -100,10 +95,43 @@ def test_gpu_slab_solver_equals_single_domain_oracle(world, size, iters, variant
     ref.solve_pressure(iters + 1)
     assert_bit_equal(got["b1"], ref.pressures_1, "odd loop P1")
     assert_bit_equal(got["b2"], ref.pressures_2, "odd loop P2")
+    thin = size[2] // world
+    split = overlap != 0 and variant in (0, 7) and size[0] % 4 == 0 and min(halo, thin) >= 4 and thin > 2 * min(halo, thin)
+    assert (int(got["overlapped"]) > 0) == split
+
+
+def test_rccl_communicator_of_one_and_loopback_rehearsal():
+    """What one GPU can show of the RCCL path: a communicator of world size 1 is created, attached and
+    destroyed (dlopen of librccl, ncclCommInitRank), and an interior rank of an 8-way run (a real Z-slab
+    context with both neighbours) runs the split-pass schedule with every received plane replaced by a
+    device copy.  The wire itself is what the driver's N = 2, 4, 8 runs exercise."""
+    import fluid_amd
+    from fluid_amd import engine as E
+    from fluid_amd import scenes
+    from fluid_amd import slab as S
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    p = fluid_amd.default_params(128, 64, 64, 0)
+    with S.SlabDriver(p, 0, 1, pressure_iterations=12, device=0) as one:
+        one.attach_rccl()          # world 1: no broadcast needed
+        one.engine.upload_image(E.CELL_TYPES, scenes.full_fluid_types((64, 64, 128)))
+        one.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((64, 64, 128)))
+        one.pressure_step()
+        whole = one.engine.download_image(E.PRESSURES_1)
+        assert np.isfinite(whole).all() and one.stat(S.STAT_EXCHANGES) == 0
+    with S.SlabDriver(p, 2, 4, pressure_iterations=40, device=0, halo_depth=4) as mid:
+        mid.attach_loopback(True, True)
+        z0, n = mid.slab
+        assert (z0, n) == (32, 16)
+        mid.upload_image(E.CELL_TYPES, scenes.full_fluid_types((n, 64, 128), z0, 64))
+        mid.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((n, 64, 128), z_begin=z0))
+        mid.pressure_step()
+        mid.engine.sync()
+        assert mid.stat(S.STAT_OVERLAPPED) > 0 and mid.stat(S.STAT_EFFECTIVE_HALO) == 4
 
 
 def test_single_rank_slab_bench_path_runs():
-    """world_size 1 through the same solver + benchmark code the multi-GPU bench uses (RCCL group
+    """world_size 1 through the same driver + benchmark code the multi-GPU bench uses (RCCL group
     of one)."""
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
@@ -111,9 +139,10 @@ def test_single_rank_slab_bench_path_runs():
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import fluid_amd\n"
-        "from fluid_amd.slab import SlabPressureSolver, init_distributed\n"
+        "from fluid_amd.slab import SlabDriver, init_distributed\n"
         "ctx = init_distributed(0)\n"
-        "s = SlabPressureSolver.create_gpu((128, 128, 64), 20, ctx)\n"
+        "s = SlabDriver.create_full_fluid((128, 128, 64), 20, ctx)\n"
+        "s.attach_rccl()\n"
         "r = s.benchmark(2, 1)\n"
         "assert r['wall_s'] > 0 and r['kernel_ms_per_sweep'] > 0, r\n"
         "print('ok', r)\n" % (ROOT, os.path.join(ROOT, "tests")))
@@ -121,3 +150,117 @@ def test_single_rank_slab_bench_path_runs():
                          timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ok" in res.stdout
+
+
+def test_c5_slab_1024x1024x64_equals_the_whole_grid_run_and_an_oracle_window():
+    """BASELINE.json configs[4] per GPU: the slab of rank 3 of 8 of the 1024 x 1024 x 512 grid (64 planes,
+    W = 1024: four x tiles per row) as a real Z-slab context under the C++ driver — deep halos of 8 planes,
+    split passes around the exchange.  Its neighbours are played by a whole-grid context on the same GPU
+    that runs the same loop in lock step: the driver's transport callback fills every plane the slab
+    "receives" from the whole grid's working buffers at the same iterate.  After 12 sweeps the slab's
+    PRESSURES_1 / _2 equal the whole-grid context's planes 192..255 bit for bit, and an oracle window inside
+    the slab agrees outside its dependence cone."""
+    import ctypes as C
+
+    import fluid_amd
+    from fluid_amd import engine as E
+    from fluid_amd import slab as S
+    from helpers import assert_bit_equal
+    from oracle_binding import OracleState
+    from test_engine_parity_gpu import c5_scene
+
+    w, h, d, iters, halo = 1024, 1024, 512, 12, 8
+    rank, world = 3, 8
+    p = fluid_amd.default_params(w, h, d, 0)
+    t, div = c5_scene((d, h, w))
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    with fluid_amd.FluidEngine(p, particle_capacity=0) as whole, \
+            S.SlabDriver(p, rank, world, pressure_iterations=iters, device=0, halo_depth=halo) as drv:
+        z0, n = drv.slab
+        assert (z0, n) == (192, 64)
+        whole.upload_image(E.CELL_TYPES, t)
+        whole.upload_image(E.DIVERGENCES, div)
+        whole.run_section("12a_clear_pressures_1")
+        whole.run_section("12b_clear_pressures_2")
+        whole.pressure_loop_begin()
+        state = {"work_exchanges": 0, "whole_k": 0, "whole_buf": 0, "error": None, "planes": 0}
+
+        def source_of(ptr, nbytes):
+            """Which loop buffer and local plane of the slab `ptr` is (ghost planes only)."""
+            for which in range(5):
+                for first in list(range(-halo, 0)) + [n]:
+                    q, plane_bytes = drv.engine.pressure_loop_plane_ptr(which, first)
+                    if q == ptr:
+                        return which, first, nbytes // plane_bytes, plane_bytes
+            raise AssertionError("received into something that is not a ghost plane of a loop buffer")
+
+        def exchange(_user, ops, count):
+            try:
+                work_seen = False
+                for i in range(count):
+                    x = ops[i]
+                    if x.flags & S.XFER_SEND:
+                        continue
+                    which, first, planes, plane_bytes = source_of(int(x.ptr), int(x.bytes))
+                    if which < 3 and not work_seen:   # planes of an iterate: bring the whole grid to it
+                        work_seen = True
+                        want = halo * state["work_exchanges"]
+                        state["work_exchanges"] += 1
+                        while state["whole_k"] < want:
+                            state["whole_buf"] = whole.pressure_loop_advance(2, False)
+                            state["whole_k"] += 2
+                        assert state["whole_buf"] == which, (state, which)
+                    whole.sync()
+                    src, _ = whole.pressure_loop_plane_ptr(which, z0 + first)
+                    rc = hip.hipMemcpy(int(x.ptr), src, planes * plane_bytes, 3)  # device to device
+                    assert rc == 0, rc
+                    state["planes"] += planes
+                return 0
+            except Exception as e:
+                state["error"] = e
+                return -3
+
+        table = S.TransportTable()
+        table.struct_bytes = C.sizeof(S.TransportTable)
+        keep = (S._EXCHANGE_FN(exchange), S._ALLREDUCE_FN(lambda _u, _v, _n: 0))
+        table.exchange, table.allreduce_max_u32 = keep
+        drv._check(drv._lib.fluid_slab_attach_transport(drv._h, C.byref(table)))
+
+        drv.engine.upload_image(E.CELL_TYPES, t[z0:z0 + n])
+        drv.engine.upload_image(E.DIVERGENCES, div[z0:z0 + n])
+        for img, arr in ((E.CELL_TYPES, t),):   # image ghost planes of the types (the mask pass reads z+-1)
+            for first in (-1, n):
+                ptr, nb = drv.engine.image_plane_ptr(img, first)
+                plane = np.ascontiguousarray(arr[z0 + first])
+                assert hip.hipMemcpy(ptr, plane.ctypes.data, nb, 1) == 0
+            drv.engine.notify_ghost_planes_written(img)
+        try:
+            drv.pressure_step()
+        finally:
+            if state["error"] is not None:
+                raise state["error"]
+        assert state["work_exchanges"] == 2 and drv.stat(S.STAT_OVERLAPPED) == 1
+        assert state["planes"] == 2 * (7 + 7 + 8) + 2 * 8
+        while state["whole_k"] < iters:
+            left = iters - state["whole_k"]
+            whole.pressure_loop_advance(2, left == 2)
+            state["whole_k"] += 2
+        whole.pressure_loop_end()
+        got = {img: drv.engine.download_image(img) for img in (E.PRESSURES_1, E.PRESSURES_2)}
+        ref = {img: whole.download_image(img)[z0:z0 + n] for img in (E.PRESSURES_1, E.PRESSURES_2)}
+    for img in got:
+        assert_bit_equal(got[img], ref[img], f"C5 slab vs whole grid, image {img}")
+    zw, zc = z0 + 4, 40   # oracle window inside the slab; exact iters planes from its cut faces
+    pw = fluid_amd.default_params(w, h, zc, 0)
+    sw = OracleState(pw, 0, iters)
+    sw.cell_types[...] = t[zw:zw + zc]
+    sw.divergences[...] = div[zw:zw + zc]
+    sw.pressures_1[...] = 1.0
+    sw.pressures_2[...] = 1.0
+    sw.solve_pressure(iters)
+    lo, hi = iters, zc - iters
+    assert_bit_equal(got[E.PRESSURES_1][4 + lo:4 + hi], sw.pressures_1[lo:hi], "C5 slab window P1")
+    assert_bit_equal(got[E.PRESSURES_2][4 + lo:4 + hi], sw.pressures_2[lo:hi], "C5 slab window P2")

@@ -1,7 +1,8 @@
-"""The whole simulation step on Z slabs (slab.SlabSimulation: section order, ghost-plane exchanges,
-particle hand-over) with world_size 2 and 3 over gloo on CPU.  The per-slab compute is the oracle on
-poisoned global arrays (tests/host_standin.py), so a missing or too-shallow exchange cannot pass; the
-result must equal the single-domain oracle bit for bit."""
+"""The whole simulation step on Z slabs with world_size 2 and 3 over gloo on CPU: section order,
+ghost-plane exchanges, particle hand-over and the sampler-halo fallback are the product's C++ driver
+(csrc/slab_driver.hip through include/fluid_slab.h).  The per-slab compute behind its callbacks is the
+oracle on poisoned global arrays (tests/host_standin.py), so a missing or too-shallow exchange cannot
+pass; the result must equal the single-domain oracle bit for bit."""
 import os
 import socket
 import sys
@@ -20,7 +21,8 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0,
+            list_capacity=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -30,19 +32,25 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
 
     import fluid_amd  # noqa: F401
     from fluid_amd import engine as E
-    from fluid_amd.slab import SlabSimulation, init_distributed, partition_z
+    from fluid_amd import slab as S
     from host_standin import HostGlobalCompute
     from test_slab_step_gpu import drift, scene_params
 
-    ctx = init_distributed(rank, backend="gloo")
+    S.init_distributed(rank, backend="gloo")
     params, cap = scene_params(size, intended)
-    slab = partition_z(size[2], world)[rank]
+    slab = S.partition_z(size[2], world)[rank]
     comp = HostGlobalCompute(params, slab, cap, iters)
-    sim = SlabSimulation(params, cap, iters, ctx, compute=comp, grouped=grouped,
-                         diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
+    if list_capacity:
+        comp.LIST_CAPACITY = list_capacity
+    if intended:
+        comp.set_diffuse_mode(E.DIFFUSE_INTENDED)
+    sim = S.SlabDriver(params, rank, world, particle_capacity=cap, pressure_iterations=iters,
+                       grouped=grouped, compute=comp,
+                       diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
+    sim.attach_torch_transport()
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
-    sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
+    sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0]), fast))
     for _ in range(steps):
         sim.run_step()
     out = {name: sim.gather_image(img) for name, img in [
@@ -50,9 +58,15 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
         ("pressures_1", E.PRESSURES_1), ("pressures_2", E.PRESSURES_2),
         ("divergences", E.DIVERGENCES), ("particle_densities", E.PARTICLE_DENSITIES_IMG)]}
     out["particles"] = sim.gather_particles()
+    stats = np.array([sim.stat(i) for i in range(8)], np.int64)
+    stats[S.STAT_SAMPLER_WIDE] = max(int(stats[S.STAT_SAMPLER_WIDE]), 0)
+    import torch
+    t = torch.from_numpy(stats.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "result.npz"), migrated=sim.migrated, **out)
+        np.savez(os.path.join(out_dir, "result.npz"), stats=t.numpy(), **out)
     dist.barrier()
+    sim.close()
     dist.destroy_process_group()
 
 
@@ -65,21 +79,57 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
 def test_slab_simulation_over_gloo_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
     import torch.multiprocessing as mp
 
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
+                       nprocs=world, join=True, start_method="spawn")
+    got = np.load(os.path.join(str(tmp_path), "result.npz"))
+    _compare_with_oracle(got, world, size, iters, steps, intended)
+    from fluid_amd import slab as S
+    assert int(got["stats"][S.STAT_MIGRATED]) > 0
+    assert int(got["stats"][S.STAT_SAMPLER_RERUNS]) == 0   # this drift stays within the default halo
+
+
+def _compare_with_oracle(got, world, size, iters, steps, intended=False, fast=0.0):
     from helpers import assert_bit_equal
     from oracle_binding import OracleState
     from test_slab_step_gpu import drift, scene_params
 
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
-                       nprocs=world, join=True, start_method="spawn")
-    got = np.load(os.path.join(str(tmp_path), "result.npz"))
     params, cap = scene_params(size, intended)
     st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
     st.run_init()
     st.run_step()
-    st.velocities_1[...] = drift(st.shape)
+    st.velocities_1[...] = drift(st.shape, fast)
     for _ in range(steps):
         st.run_step()
     for name in ("cell_types", "particle_densities", "divergences", "pressures_1", "pressures_2",
                  "velocities_1", "particles"):
         assert_bit_equal(got[name], getattr(st, name), f"{world} slabs, {name}")
-    assert int(got["migrated"]) > 0
+
+
+@pytest.mark.parametrize("world,size,fast,expect_wide", [
+    (2, (16, 12, 16), 55.0, False),    # 2.2 cells per step: 07 is redone with the image's four ghost planes
+    (3, (12, 10, 24), 260.0, True),    # 10.4 cells per step, slabs of 8 planes: beyond the image's ghost
+                                       # planes and beyond the neighbouring slab — the wide source
+])
+def test_fast_flow_widens_the_sampler_halo_and_never_fails(world, size, fast, expect_wide, tmp_path):
+    """back-traces and particles are never clamped (advect.comp:63-78, particles.comp:45-51).
+    A z-drift of several cells per step makes 07 reach beyond the ghost planes exchanged as a matter of
+    course: one rank's kernel flags it, ALL ranks redo the pass with the halo the velocities call for
+    (from the image's ghost planes, or — beyond four — from a wide source filled by whoever owns the
+    planes), and particles that cross more than one slab in a step are passed on from neighbour to
+    neighbour.  Bit-identical to the single-domain oracle; nothing raises, nobody hangs."""
+    import torch.multiprocessing as mp
+
+    from fluid_amd import slab as S
+
+    iters, steps = 4, 3
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, True, str(tmp_path), False,
+                                      fast, 64),
+                       nprocs=world, join=True, start_method="spawn")
+    got = np.load(os.path.join(str(tmp_path), "result.npz"))
+    _compare_with_oracle(got, world, size, iters, steps, fast=fast)
+    stats = got["stats"]
+    assert int(stats[S.STAT_SAMPLER_RERUNS]) > 0
+    assert (int(stats[S.STAT_SAMPLER_WIDE]) > 0) == expect_wide
+    assert int(stats[S.STAT_MIGRATED]) > 0
+    if expect_wide:  # the list capacity of 64 entries is smaller than what crosses a face in one step
+        assert int(stats[S.STAT_MIGRATE_ROUNDS]) > steps + 1

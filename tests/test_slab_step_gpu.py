@@ -1,6 +1,6 @@
-"""The whole simulation step on Z slabs (slab.SlabSimulation) with 2 and 3 ranks on the one GPU of the
-test box (planes and particle lists travel over gloo through host staging), against the single-domain
-oracle: cell types, velocities, pressures and the particle buffer bit for bit after several steps of a
+"""The whole simulation step on Z slabs (the C++ driver of include/fluid_slab.h on the HIP engine) with 2
+and 3 ranks on the one GPU of the test box (planes and particle lists travel over gloo through host
+staging), against the single-domain oracle: cell types, velocities, pressures and the particle buffer bit for bit after several steps of a
 scene whose water and particles cross the slab faces."""
 import os
 import socket
@@ -41,15 +41,16 @@ def scene_params(size, intended=False):
     return p, cap
 
 
-def drift(shape):
-    """Initial velocity field uploaded after init: a steady drift along +z (and a little -x)."""
+def drift(shape, fast=0.0):
+    """Initial velocity field uploaded after init: a steady drift along +z (and a little -x).
+    fast: the z speed, in cells per time unit (default 5 = 0.2 cells per step of this scene)."""
     v = np.zeros(shape + (4,), np.float32)
-    v[..., 2] = 5.0
+    v[..., 2] = fast if fast else 5.0
     v[..., 0] = -1.5
     return v
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -60,18 +61,20 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
 
     import fluid_amd  # noqa: F401
     from fluid_amd import engine as E
-    from fluid_amd.slab import DistContext, SlabSimulation
+    from fluid_amd import slab as S
     from test_slab_step_gpu import drift, scene_params
 
     dist.init_process_group(backend="gloo")
-    torch.cuda.set_device(0)
-    ctx = DistContext(rank, world, torch.device("cuda", 0), "gloo")
     params, cap = scene_params(size, intended)
-    sim = SlabSimulation(params, cap, iters, ctx, transport="staged", grouped=grouped,
-                         diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
+    # the product's C++ driver on the HIP engine; only the wire differs from an N-GPU run: the ranks
+    # share GPU 0, where RCCL refuses to run, so the planes are staged through the host over gloo
+    sim = S.SlabDriver(params, rank, world, particle_capacity=cap, pressure_iterations=iters, device=0,
+                       grouped=grouped,
+                       diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
+    sim.attach_torch_transport(device_memory=True)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
-    sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0])))
+    sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0]), fast))
     for _ in range(steps):
         sim.run_step()
     out = {name: sim.gather_image(img) for name, img in [
@@ -79,12 +82,30 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
         ("pressures_1", E.PRESSURES_1), ("pressures_2", E.PRESSURES_2),
         ("divergences", E.DIVERGENCES), ("particle_densities", E.PARTICLE_DENSITIES_IMG)]}
     out["particles"] = sim.gather_particles()
-    migrated = sim.migrated
+    t = torch.tensor([sim.stat(i) for i in range(8)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "result.npz"), migrated=migrated, **out)
+        np.savez(os.path.join(out_dir, "result.npz"), stats=t.numpy(), **out)
     dist.barrier()
     sim.close()
     dist.destroy_process_group()
+
+
+def _check(got, world, size, iters, steps, intended=False, fast=0.0):
+    from helpers import assert_bit_equal
+    from oracle_binding import OracleState
+
+    params, cap = scene_params(size, intended)
+    st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
+    st.run_init()
+    st.run_step()
+    st.velocities_1[...] = drift(st.shape, fast)
+    for _ in range(steps):
+        st.run_step()
+    for name in ("cell_types", "particle_densities", "divergences", "pressures_1", "pressures_2",
+                 "velocities_1", "particles"):
+        assert_bit_equal(got[name], getattr(st, name), f"{world} slabs, {name}")
+    return st
 
 
 @pytest.mark.parametrize("world,size,iters,steps,grouped,intended", [
@@ -96,24 +117,41 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
 def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
     import torch.multiprocessing as mp
 
-    from helpers import assert_bit_equal
-    from oracle_binding import OracleState
+    from fluid_amd import slab as S
 
     mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
-    params, cap = scene_params(size, intended)
-    st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
-    st.run_init()
-    st.run_step()
-    st.velocities_1[...] = drift(st.shape)
-    for _ in range(steps):
-        st.run_step()
-    for name in ("cell_types", "particle_densities", "divergences", "pressures_1", "pressures_2",
-                 "velocities_1", "particles"):
-        assert_bit_equal(got[name], getattr(st, name), f"{world} slabs, {name}")
+    st = _check(got, world, size, iters, steps, intended)
     # the scene did what the test is for: water on both sides of a face, particles changed owner
     d = size[2]
     face = d // world
     assert np.any(st.cell_types[face - 1] == 2) and np.any(st.cell_types[face] == 2)
-    assert int(got["migrated"]) > 0
+    assert int(got["stats"][S.STAT_MIGRATED]) > 0
+    assert int(got["stats"][S.STAT_SAMPLER_RERUNS]) == 0
+
+
+@pytest.mark.parametrize("world,size,fast,expect_wide", [
+    (2, (32, 24, 16), 55.0, False),    # 2.2 cells per step: more than the default two ghost planes serve
+    (3, (64, 16, 24), 260.0, True),    # 10.4 cells per step across slabs of 8 planes: the wide source
+])
+def test_fast_flow_widens_the_sampler_halo_and_never_fails(world, size, fast, expect_wide, tmp_path):
+    """SURVEY.md F6 on the engine: a z-drift of more than a cell per step.  One rank's 07 kernel flags a
+    tap beyond its ghost planes; every rank redoes the pass with the halo max |v.z| dt calls for — from
+    the image's own ghost planes, or from the wide source filled by whoever owns the planes — and
+    particles that cross more than one slab in a step travel from neighbour to neighbour.  Bit-identical
+    to the single-domain oracle."""
+    import torch.multiprocessing as mp
+
+    from fluid_amd import slab as S
+
+    iters, steps = 6, 3
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, True, str(tmp_path), False,
+                                      fast),
+                       nprocs=world, join=True, start_method="spawn")
+    got = np.load(os.path.join(str(tmp_path), "result.npz"))
+    _check(got, world, size, iters, steps, fast=fast)
+    stats = got["stats"]
+    assert int(stats[S.STAT_SAMPLER_RERUNS]) > 0
+    assert (int(stats[S.STAT_SAMPLER_WIDE]) > 0) == expect_wide
+    assert int(stats[S.STAT_MIGRATED]) > 0

@@ -178,7 +178,19 @@ struct fluid_ctx {
     uint8_t* pbricks() const { return arena + pbricks_offset; }
     const uint8_t* early_or_null() const { return early_in_use ? early() : nullptr; }
     uint32_t* flags() const { return reinterpret_cast<uint32_t*>(arena + flags_offset); }
-    Leaver* leavers() const { return reinterpret_cast<Leaver*>(arena + leavers_offset); }
+    // list 0 / 1: leavers to send down / up; 2 / 3: received from the neighbour below / above
+    Leaver* leavers(int list) const {
+        return reinterpret_cast<Leaver*>(arena + leavers_offset) + (uint64_t)list * leavers_capacity;
+    }
+    MigrateLists migrate_lists() const {
+        MigrateLists m;
+        m.send[0] = leavers(0);
+        m.send[1] = leavers(1);
+        m.count[0] = flags() + 28;
+        m.count[1] = flags() + 29;
+        m.capacity = leavers_capacity;
+        return m;
+    }
     // bookkeeping for the fast path: call whenever an image's device contents change
     void touched(int image) {
         if (image == FLUID_IMG_CELL_TYPES) {
@@ -328,13 +340,14 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     }
     L.flags_offset = off;
     off = align_up(off + 256, kAlign);
-    // room for every particle to leave in one step is never needed; a quarter of them (at least 64 Ki
-    // entries) is generous, and an overflow is reported, not ignored
+    // Four lists (send down / up, received from below / above) of capacity / 16 entries each, at least
+    // 64 Ki: 8 bytes per particle slot.  More leavers than that in one step take more hand-over rounds
+    // (fluid_particles_collect leaves them in place and says so), they are never dropped.
     const bool slab = dl != p.fluid_size[2];
     L.leavers_capacity =
-        slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(capacity / 4, 65536), 0x7FFFFFFFu) : 0;
+        slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(capacity / 16, 65536), 0x0FFFFFFFu) : 0;
     L.leavers_offset = off;
-    off = align_up(off + (uint64_t)L.leavers_capacity * sizeof(Leaver), kAlign);
+    off = align_up(off + 4ull * L.leavers_capacity * sizeof(Leaver), kAlign);
     L.surf_cells = 0;
     for (int i = 0; i < 4; i++) L.surf_offset[i] = 0;
     if (wants_surface(info)) {
@@ -1492,6 +1505,11 @@ int fluid_pressure_loop_max_sweeps(fluid_ctx* c) {
     return fuse_enabled(c) ? 2 : 1;
 }
 
+int fluid_pressure_loop_available(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    return fast_loop_possible(c) ? 1 : 0;
+}
+
 int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermediate,
                                 int* written_buffer) {
     if (!c) return FLUID_ERR_INVALID_ARG;
@@ -1995,12 +2013,13 @@ int fluid_sampler_reach(fluid_ctx* c, uint32_t* planes) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float vmax;
     memcpy(&vmax, &bits, 4);
-    // advect.comp:75-77: the back-traced point lies |v.z * dt| from the face position, v.z a trilinear
-    // blend of texels (each |.| <= vmax, up to rounding: the factor), and its two z taps are the planes
-    // around it: floor(|v.z| * dt) + 2 planes from the cell's own; one more for the roundings.
+    // advect.comp:75-77: the back-traced point lies x = |v.z * dt| from the face position (v.z a trilinear
+    // blend of texels, each |.| <= vmax up to rounding: the factor) and its two z taps are the planes
+    // around it, floor(x) + 1 planes from the cell's own at most; one more for the roundings of the
+    // coordinate arithmetic.  (The driver checks the flag again after the redone pass in any case.)
     const double reach = (double)vmax * (double)fabsf(c->pk.dt) * (1.0 + 1e-5);
     uint32_t n = (uint32_t)c->g.Dg;
-    if (vmax == vmax && reach < (double)c->g.Dg) n = std::min<uint32_t>((uint32_t)reach + 3u, n);
+    if (vmax == vmax && reach < (double)c->g.Dg) n = std::min<uint32_t>((uint32_t)reach + 2u, n);
     *planes = n;
     return FLUID_OK;
 }
@@ -2070,40 +2089,73 @@ int fluid_run_advect_wide(fluid_ctx* c, int with_forces) {
     return tm.end();
 }
 
-int fluid_particles_collect_leavers(fluid_ctx* c, void** device_list, uint32_t* count) {
+// ---- particle hand-over between Z-neighbours ------------------------------------------------------------
+int fluid_particles_migrate_list(fluid_ctx* c, int which, void** device_list, uint32_t* capacity) {
     if (!c) return FLUID_ERR_INVALID_ARG;
-    if (!device_list || !count) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
-    HIP_TRY(c, hipSetDevice(c->device));
-    *device_list = c->leavers();
-    *count = 0;
-    if (!c->is_slab || c->particle_capacity == 0) return FLUID_OK;
-    uint32_t* counter = c->flags() + 1;
-    HIP_TRY(c, hipMemsetAsync(counter, 0, 4, c->stream));
-    const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
-    hipLaunchKernelGGL(k_particles_collect_leavers, dim3(blocks), dim3(256), 0, c->stream,
-                       c->particles(), c->particle_capacity, c->g, c->leavers(), counter,
-                       c->leavers_capacity);
-    HIP_TRY(c, hipGetLastError());
-    uint32_t n = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n, counter, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n > c->leavers_capacity)
-        return c->fail(FLUID_ERR_OUT_OF_MEMORY,
-                       "%u particles left the slab in one step, the migration list holds %u", n,
-                       c->leavers_capacity);
-    *count = n;
+    if (!device_list || !capacity) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (which < 0 || which > 3) return c->fail(FLUID_ERR_INVALID_ARG, "migration list %d", which);
+    *device_list = c->leavers(which);
+    *capacity = c->leavers_capacity;
     return FLUID_OK;
 }
 
-int fluid_particles_adopt(fluid_ctx* c, const void* device_list, uint32_t count) {
+static int read_migrate_counts(fluid_ctx* c, uint32_t counts[2], uint32_t* left_behind) {
+    uint32_t n[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(n, c->flags() + 28, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t over = 0;
+    for (int d = 0; d < 2; d++) {
+        if (n[d] > c->leavers_capacity) {
+            over += n[d] - c->leavers_capacity;
+            n[d] = c->leavers_capacity;
+            // the device counter keeps counting past the capacity: put it back for whoever appends next
+            HIP_TRY(c, hipMemcpyAsync(c->flags() + 28 + d, &c->leavers_capacity, 4, hipMemcpyHostToDevice,
+                                      c->stream));
+        }
+        counts[d] = n[d];
+    }
+    if (left_behind) *left_behind = over;
+    return FLUID_OK;
+}
+
+int fluid_particles_collect(fluid_ctx* c, int reset_lists, uint32_t counts[2], uint32_t* left_behind) {
     if (!c) return FLUID_ERR_INVALID_ARG;
-    if (count == 0) return FLUID_OK;
-    if (!device_list) return c->fail(FLUID_ERR_INVALID_ARG, "null leaver list");
+    if (!counts || !left_behind) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
     HIP_TRY(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_particles_adopt, dim3((count + 255) / 256), dim3(256), 0, c->stream,
-                       c->particles(), c->particle_capacity, c->g,
-                       static_cast<const Leaver*>(device_list), count);
+    counts[0] = counts[1] = 0;
+    *left_behind = 0;
+    if (!c->is_slab || c->particle_capacity == 0) return FLUID_OK;
+    if (reset_lists) HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));
+    const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
+    hipLaunchKernelGGL(k_particles_collect_leavers, dim3(blocks), dim3(256), 0, c->stream,
+                       c->particles(), c->particle_capacity, c->g, c->migrate_lists());
     HIP_TRY(c, hipGetLastError());
+    return read_migrate_counts(c, counts, left_behind);
+}
+
+int fluid_particles_adopt_received(fluid_ctx* c, uint32_t from_below, uint32_t from_above,
+                                   uint32_t forwarded[2]) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!forwarded) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (from_below > c->leavers_capacity || from_above > c->leavers_capacity)
+        return c->fail(FLUID_ERR_INVALID_ARG, "%u / %u received entries, the lists hold %u", from_below,
+                       from_above, c->leavers_capacity);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));  // the send lists have been sent
+    const uint32_t n[2] = {from_below, from_above};
+    for (int src = 0; src < 2; src++) {
+        if (n[src] == 0) continue;
+        // from below: travelling up (dir 1); from above: travelling down (dir 0)
+        hipLaunchKernelGGL(k_particles_adopt, dim3((n[src] + 255) / 256), dim3(256), 0, c->stream,
+                           c->particles(), c->particle_capacity, c->g, c->leavers(2 + src), n[src],
+                           src == 0 ? 1 : 0, c->migrate_lists());
+        HIP_TRY(c, hipGetLastError());
+    }
+    uint32_t over = 0;
+    int rc = read_migrate_counts(c, forwarded, &over);
+    if (rc) return rc;
+    if (over)  // cannot happen while every rank's lists have the same capacity (forwarded <= received)
+        return c->fail(FLUID_ERR_OUT_OF_MEMORY, "%u forwarded particles did not fit the send lists", over);
     return FLUID_OK;
 }
 

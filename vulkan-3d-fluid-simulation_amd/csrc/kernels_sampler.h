@@ -332,34 +332,53 @@ __global__ void k_particles_filter(float4* __restrict__ particles, uint64_t capa
     if (!slab_owns(g, particles[i].z)) particles[i] = tombstone();
 }
 // A "leaver": a particle this slab holds but no longer owns (14_particles moved it across a face).
+// Hand-over is between Z-neighbours: a leaver travels down (towards z = 0) or up, its new owner adopts
+// it, and a slab that receives one it does not own either (the particle crossed more than one slab in a
+// step) passes it on in the same direction.  Lists of 32-byte entries; dir 0 = down, 1 = up.
 struct Leaver {
     float4 data;
     uint32_t index, pad0, pad1, pad2;
 };
+struct MigrateLists {
+    Leaver* send[2];      // [down, up]
+    uint32_t* count[2];   // entries appended so far
+    uint32_t capacity;    // entries per list
+};
+__device__ __forceinline__ bool migrate_append(const MigrateLists& m, int dir, float4 data, uint32_t index) {
+    const uint32_t slot = atomicAdd(m.count[dir], 1u);
+    if (slot >= m.capacity) return false;  // count > capacity tells the host; the entry is not stored
+    Leaver l;
+    l.data = data;
+    l.index = index;
+    l.pad0 = l.pad1 = l.pad2 = 0u;
+    m.send[dir][slot] = l;
+    return true;
+}
+// list the particles this slab holds but does not own and bury their slots; a particle that finds its
+// list full stays where it is (the host runs another round)
 __global__ void k_particles_collect_leavers(float4* __restrict__ particles, uint64_t capacity,
-                                            GridK g, Leaver* __restrict__ list,
-                                            uint32_t* __restrict__ counter, uint32_t list_capacity) {
+                                            GridK g, MigrateLists m) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
     const float4 q = particles[i];
-    if (is_tombstone(q) || slab_owns(g, q.z)) return;
-    const uint32_t slot = atomicAdd(counter, 1u);
-    if (slot < list_capacity) {  // else: counter > capacity tells the host to retry with more room
-        Leaver l;
-        l.data = q;
-        l.index = (uint32_t)i;
-        l.pad0 = l.pad1 = l.pad2 = 0u;
-        list[slot] = l;
-        particles[i] = tombstone();
-    }
+    if (is_tombstone(q)) return;
+    const int pl = particle_owner_plane(q.z, g.Dg) - g.z0;
+    if ((unsigned)pl < (unsigned)g.Dl) return;
+    if (migrate_append(m, pl < 0 ? 0 : 1, q, (uint32_t)i)) particles[i] = tombstone();
 }
-// adopt the leavers of all ranks that now belong to this slab
+// entries received from the neighbour below travel up (dir 1), those from above travel down (dir 0):
+// adopt what this slab owns, pass the rest on
 __global__ void k_particles_adopt(float4* __restrict__ particles, uint64_t capacity, GridK g,
-                                  const Leaver* __restrict__ list, uint32_t count) {
+                                  const Leaver* __restrict__ list, uint32_t count, int dir,
+                                  MigrateLists m) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const Leaver l = list[i];
-    if (l.index < capacity && slab_owns(g, l.data.z)) particles[l.index] = l.data;
+    if (l.index >= capacity) return;
+    if (slab_owns(g, l.data.z))
+        particles[l.index] = l.data;
+    else
+        migrate_append(m, dir, l.data, l.index);
 }
 
 // 00_init_particles/init_particles.comp:27-50

@@ -82,7 +82,8 @@ EXPORTED_SYMBOLS = [
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
     "fluid_pressure_loop_advance_part", "fluid_pressure_loop_edge_stream",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
-    "fluid_slab_status", "fluid_particles_collect_leavers", "fluid_particles_adopt",
+    "fluid_slab_status", "fluid_particles_migrate_list", "fluid_particles_collect",
+    "fluid_particles_adopt_received", "fluid_pressure_loop_available",
     "fluid_get_geometry", "fluid_set_option", "fluid_count_nonfinite",
     "fluid_set_sampler_halo", "fluid_sampler_reach", "fluid_sampler_wide_begin",
     "fluid_sampler_wide_plane_ptr", "fluid_run_advect_wide",
@@ -174,8 +175,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp),
                                                     C.POINTER(u64)]),
         "fluid_slab_status": (C.c_int, [vp, C.POINTER(u32)]),
-        "fluid_particles_collect_leavers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(u32)]),
-        "fluid_particles_adopt": (C.c_int, [vp, vp, u32]),
+        "fluid_particles_migrate_list": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(u32)]),
+        "fluid_particles_collect": (C.c_int, [vp, C.c_int, C.POINTER(u32 * 2), C.POINTER(u32)]),
+        "fluid_particles_adopt_received": (C.c_int, [vp, u32, u32, C.POINTER(u32 * 2)]),
+        "fluid_pressure_loop_available": (C.c_int, [vp]),
         "fluid_get_geometry": (C.c_int, [vp, C.POINTER(u32 * 3), C.POINTER(u32), C.POINTER(u32),
                                          C.POINTER(u64)]),
         "fluid_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
@@ -235,6 +238,24 @@ class FluidEngine:
         self.diffuse_mode = DIFFUSE_REFERENCE_EXACT
         self.solver, self.sor_omega = 0, 1.0
         self.surface_diffuse_steps = int(surface_diffuse_steps) if surface_diffuse_steps else 4
+        self._read_geometry()
+
+    @classmethod
+    def from_handle(cls, handle: int, params: FluidParams) -> "FluidEngine":
+        """A view of a context somebody else owns (the slab driver's, fluid_slab_engine): every method
+        works, close() leaves the context alone."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self.surface_prep = False
+        self.params = params.copy()
+        self.pressure_iterations, self.diffuse_mode = 200, DIFFUSE_REFERENCE_EXACT
+        self.solver, self.sor_omega, self.surface_diffuse_steps = 0, 1.0, 4
+        self._read_geometry()
+        return self
+
+    def _read_geometry(self):
         size = (C.c_uint32 * 3)()
         z0, zc, cap = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self._check(self._lib.fluid_get_geometry(self._h, C.byref(size), C.byref(z0), C.byref(zc),
@@ -264,7 +285,8 @@ class FluidEngine:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._lib.fluid_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.fluid_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -540,15 +562,6 @@ class FluidEngine:
         v = C.c_uint32()
         self._check(self._lib.fluid_slab_status(self._h, C.byref(v)))
         return bool(v.value)
-
-    def particles_collect_leavers(self):
-        """Returns (device pointer of the leaver list, count)."""
-        ptr, n = C.c_void_p(), C.c_uint32()
-        self._check(self._lib.fluid_particles_collect_leavers(self._h, C.byref(ptr), C.byref(n)))
-        return int(ptr.value or 0), int(n.value)
-
-    def particles_adopt(self, device_ptr: int, count: int):
-        self._check(self._lib.fluid_particles_adopt(self._h, device_ptr, count))
 
     def notify_image_written(self, image_id: int):
         self._check(self._lib.fluid_notify_image_written(self._h, image_id))

@@ -1,18 +1,20 @@
-"""Z-slab decomposition of the pressure solve across GPUs — one process per GPU.
+"""ctypes binding of include/fluid_slab.h — the multi-GPU driver (one process per GPU, Z slabs).
 
-The reference is single-GPU (main.cpp:43-48); this is the multi-GPU form of its hot loop
-(`12_solve_pressure x N`, fluid_flow_sections.h:300-313).  The global grid is cut into contiguous
-Z slabs (z is the slowest index, so a slab and each XY plane are contiguous in memory); every rank
-owns `z_count` planes plus one ghost plane per side.  A 7-point sweep reads z±1, so after every
-sweep each rank sends its first/last owned plane of the buffer just written to its lower/upper
-neighbour and receives their planes into its ghost planes: point-to-point Send/Recv with the two
-Z-neighbours only (2 of the 7 xGMI links per GPU), W*H*4 bytes per message — no collective on the
-data path.  `torch.distributed` is the transport (backend "nccl" = RCCL on GPU tensors that alias
-the engine's device memory; backend "gloo" on CPU tensors in the tests) — the decomposition and the
-exchange schedule below are the same code in both cases, only the per-slab compute differs.
+The schedule (which ghost planes travel when, deep halos and split passes of the Jacobi loop, particle
+hand-over, the wider sampler halo for fast flows) is C++ in csrc/slab_driver.hip; planes travel by RCCL
+Send/Recv issued from there.  This module is plumbing: it loads the symbols, wraps a driver in a class
+whose methods follow main.cpp's frame loop (run_init once, run_step per frame), and offers
+`torch.distributed` as
 
-Ghost planes at a domain face are never written and stay 0 (= the reference's out-of-bounds load).
+  * the bootstrap of the RCCL communicator (rank 0's unique id is broadcast over the process group the
+    launcher set up; the data path never touches torch), and
+  * a callback transport (fluid_slab_transport) for runs without RCCL: the multi-process CPU tests drive
+    the same C++ schedule over gloo on host memory, and several ranks can rehearse on ONE GPU with the
+    planes staged through the host.
+
+The reference is single-GPU (main.cpp:43-48).
 """
+import ctypes as C
 import os
 import time
 from dataclasses import dataclass
@@ -21,20 +23,134 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import engine as E
-from .params import FluidParams, default_params
+from .params import PARAMS_BYTES, FluidParams, default_params
+
+OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH = 0, 1, 2
+OPT_OVERLAP, OPT_HALO_DEPTH, OPT_SAMPLER_HALO = 0, 1, 2
+(STAT_EXCHANGES, STAT_OVERLAPPED, STAT_MIGRATED, STAT_SAMPLER_RERUNS, STAT_SAMPLER_WIDE,
+ STAT_EFFECTIVE_HALO, STAT_SAMPLER_HALO, STAT_MIGRATE_ROUNDS) = range(8)
+XFER_SEND, XFER_HOST_MEMORY = 1, 2
+RCCL_ID_BYTES = 128
+LOOP_PART_EDGES, LOOP_PART_INTERIOR = 1, 2
+
+# every symbol include/fluid_slab.h declares
+EXPORTED_SYMBOLS = [
+    "fluid_slab_partition", "fluid_slab_create", "fluid_slab_create_custom", "fluid_slab_destroy",
+    "fluid_slab_last_error", "fluid_slab_engine", "fluid_slab_get_slab", "fluid_slab_rccl_unique_id",
+    "fluid_slab_attach_rccl", "fluid_slab_attach_transport", "fluid_slab_attach_loopback",
+    "fluid_slab_run_init", "fluid_slab_run_step", "fluid_slab_pressure_step", "fluid_slab_solve",
+    "fluid_slab_exchange_image", "fluid_slab_set_option", "fluid_slab_get_stat",
+]
+
+
+class SlabCreateInfo(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32),
+        ("device", C.c_int32), ("params_blob", C.c_void_p), ("particle_capacity", C.c_uint64),
+        ("pressure_iterations", C.c_uint32), ("halo_depth", C.c_uint32), ("overlap", C.c_int32),
+        ("section_list", C.c_uint32), ("diffuse_mode", C.c_int32), ("sampler_halo", C.c_uint32),
+    ]
+
+
+class Xfer(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_uint64), ("peer", C.c_int32), ("flags", C.c_uint32)]
+
+
+class LoopBuffer(C.Structure):
+    _fields_ = [("which", C.c_int32), ("planes", C.c_uint32)]
+
+
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Xfer), C.c_uint32)
+_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32)
+
+
+class TransportTable(C.Structure):
+    _fields_ = [("struct_bytes", C.c_uint32), ("reserved", C.c_uint32), ("user", C.c_void_p),
+                ("exchange", _EXCHANGE_FN), ("allreduce_max_u32", _ALLREDUCE_FN)]
+
+
+_vp, _i32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+_pvp, _pu32, _pu64 = C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_BACKEND_FIELDS = [   # order = include/fluid_slab.h: fluid_slab_backend
+    ("run_section", [C.c_int]),
+    ("run_section_group", [C.c_int, _u32]),
+    ("image_planes", [C.c_int, _i32, _u32, _pvp, _pu64]),
+    ("ghost_planes_written", [C.c_int]),
+    ("loop_limits", [_pu32, _pu32]),
+    ("loop_begin", [_u32, C.POINTER(LoopBuffer), _pu32]),
+    ("loop_halo_exchanged", [_u32, C.c_int]),
+    ("loop_advance", [_u32, _u32, C.c_int, C.c_int, _i32, _i32, C.POINTER(C.c_int)]),
+    ("loop_end", []),
+    ("loop_planes", [C.c_int, _i32, _u32, _pvp, _pu64]),
+    ("slab_status", [_pu32]),
+    ("set_sampler_halo", [_u32]),
+    ("sampler_reach", [_pu32]),
+    ("sampler_wide_begin", [_u32, _u32]),
+    ("sampler_wide_planes", [_i32, _u32, _pvp, _pu64]),
+    ("run_advect_wide", [C.c_int]),
+    ("migrate_list", [C.c_int, _pvp, _pu32]),
+    ("collect", [C.c_int, _pu32, _pu32]),
+    ("adopt_received", [_u32, _u32, _pu32]),
+    ("sync", []),
+]
+_BACKEND_FN = {name: C.CFUNCTYPE(C.c_int, C.c_void_p, *args) for name, args in _BACKEND_FIELDS}
+
+
+class BackendTable(C.Structure):
+    _fields_ = ([("struct_bytes", C.c_uint32), ("reserved", C.c_uint32), ("user", C.c_void_p)]
+                + [(name, _BACKEND_FN[name]) for name, _ in _BACKEND_FIELDS])
+
+
+_declared = False
+
+
+def _lib():
+    """libfluid_engine.so with the fluid_slab_* signatures declared."""
+    global _declared
+    lib = E.load_library()
+    if not _declared:
+        vp = C.c_void_p
+        sig = {
+            "fluid_slab_partition": (C.c_int, [_u32, _u32, _u32, _pu32, _pu32]),
+            "fluid_slab_create": (C.c_int, [_pvp, C.POINTER(SlabCreateInfo)]),
+            "fluid_slab_create_custom": (C.c_int, [_pvp, C.POINTER(SlabCreateInfo),
+                                                   C.POINTER(BackendTable)]),
+            "fluid_slab_destroy": (None, [vp]),
+            "fluid_slab_last_error": (C.c_char_p, [vp]),
+            "fluid_slab_engine": (vp, [vp]),
+            "fluid_slab_get_slab": (C.c_int, [vp, _pu32, _pu32]),
+            "fluid_slab_rccl_unique_id": (C.c_int, [vp]),
+            "fluid_slab_attach_rccl": (C.c_int, [vp, vp]),
+            "fluid_slab_attach_transport": (C.c_int, [vp, C.POINTER(TransportTable)]),
+            "fluid_slab_attach_loopback": (C.c_int, [vp, C.c_int, C.c_int]),
+            "fluid_slab_run_init": (C.c_int, [vp]),
+            "fluid_slab_run_step": (C.c_int, [vp]),
+            "fluid_slab_pressure_step": (C.c_int, [vp]),
+            "fluid_slab_solve": (C.c_int, [vp, _u32]),
+            "fluid_slab_exchange_image": (C.c_int, [vp, C.c_int, _u32]),
+            "fluid_slab_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
+            "fluid_slab_get_stat": (C.c_int, [vp, C.c_int, _pu64]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _declared = True
+    return lib
 
 
 def partition_z(depth: int, world: int) -> List[Tuple[int, int]]:
-    """Balanced contiguous split of `depth` planes over `world` ranks: (z_begin, z_count) per rank.
-    The first depth % world ranks get one extra plane.  Every rank must own at least one plane."""
+    """fluid_slab_partition for every rank: (z_begin, z_count); the first depth % world ranks get one
+    plane more."""
     if world < 1 or depth < world:
         raise ValueError(f"cannot split {depth} planes over {world} ranks")
-    base, extra = divmod(depth, world)
-    out, z = [], 0
+    lib = _lib()
+    out = []
     for r in range(world):
-        n = base + (1 if r < extra else 0)
-        out.append((z, n))
-        z += n
+        z0, n = C.c_uint32(), C.c_uint32()
+        if lib.fluid_slab_partition(depth, world, r, C.byref(z0), C.byref(n)) != 0:
+            raise ValueError(f"cannot split {depth} planes over {world} ranks")
+        out.append((int(z0.value), int(n.value)))
     return out
 
 
@@ -44,830 +160,379 @@ class DistContext:
     world: int
     device: object  # torch.device
     backend: str
-    group: object = None
 
 
 def init_distributed(local_rank: int = 0, backend: Optional[str] = None) -> DistContext:
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  The group is
+    used for bootstrap and measurement only (unique id broadcast, barriers, MAX of the timings): gloo is
+    enough, and is the default when no backend is asked for."""
     import torch
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    use_gpu = backend in (None, "nccl") and torch.cuda.is_available()
-    if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+    use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-    else:
-        device = torch.device("cpu")
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
     if not dist.is_initialized():
-        kw = {"device_id": device} if use_gpu else {}
-        dist.init_process_group(backend=backend, **kw)
-    return DistContext(dist.get_rank(), dist.get_world_size(), device, backend)
+        dist.init_process_group(backend=backend or "gloo")
+    return DistContext(dist.get_rank(), dist.get_world_size(), device, dist.get_backend())
 
 
-# ---- per-slab compute backends ---------------------------------------------------------------------
-class GpuSlabCompute:
-    """The HIP engine on one slab.  Device memory is a torch tensor (so RCCL can address the halo
-    planes as tensor views) handed to the engine as its arena; kernels run on torch's current
-    stream, which is also the stream the NCCL ops synchronise with."""
+# ---- callback transport over torch.distributed --------------------------------------------------------
+class TorchDistTransport:
+    """fluid_slab_transport over a torch.distributed process group (gloo): point-to-point between the
+    ranks the driver names, a MAX all-reduce for its 4-byte flags.  Host memory is addressed in place;
+    device memory (`device_memory=True`: several ranks of a rehearsal sharing one GPU, where RCCL refuses
+    to run) is staged through host buffers with hipMemcpy."""
 
-    def __init__(self, params: FluidParams, slab: Tuple[int, int], device, pressure_kernel: int = 0,
-                 particle_capacity: int = 0, pressure_iterations: int = 200, edge_stream: bool = False):
+    def __init__(self, device_memory: bool = False):
         import torch
+        import torch.distributed as dist
 
-        self.torch = torch
-        self.device = device
-        nbytes = E.FluidEngine.required_arena_bytes(params, particle_capacity, slab=slab)
-        if nbytes == 0:
-            raise RuntimeError("invalid slab geometry")
-        # One explicit side stream, made torch's current stream for this process: the engine's
-        # kernels and the communicator's stream-ordering both follow it.  (The legacy null stream
-        # has handle 0, which the C ABI reads as "create your own".)
-        self.stream = torch.cuda.Stream(device=device)
-        self.comm_stream = None  # created by the first overlapped exchange
-        torch.cuda.set_stream(self.stream)
-        self.arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
-        base = self.arena.data_ptr()
-        self._pad = (-base) % 256
-        assert self.stream.cuda_stream != 0
-        self.engine = E.FluidEngine(
-            params, particle_capacity=particle_capacity, pressure_iterations=pressure_iterations,
-            device=device.index if device.index is not None else -1,
-            slab=slab, stream=self.stream.cuda_stream,
-            arena=base + self._pad, arena_bytes=nbytes)
-        self.engine.set_option(E.OPT_PRESSURE_KERNEL, pressure_kernel)
-        # FLUID_OPT_EDGE_STREAM: the EDGES launches of split passes run on a second engine stream beside
-        # the INTERIOR launches; exchanges are then ordered against that stream (comm_scope / comm_join)
-        self.edge_ext = None
-        if edge_stream or os.environ.get("FLUID_SLAB_EDGE_STREAM") == "1":
-            self.engine.set_option(E.OPT_EDGE_STREAM, 1)
-            self.edge_ext = torch.cuda.ExternalStream(self.engine.pressure_loop_edge_stream(),
-                                                      device=device)
-        self._base = base
-        # working-buffer loop (fluid_pressure_loop_*) when the engine offers it for this grid
-        self.fast = params.size[0] % 4 == 0 and pressure_kernel in (0, 5, 6, 7)
+        self.torch, self.dist = torch, dist
+        self.device_memory = device_memory
+        self.error = None
+        self._hip = None
+        if device_memory:
+            self._hip = C.CDLL("libamdhip64.so")
+            self._hip.hipMemcpy.restype = C.c_int
+            self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.table = TransportTable()
+        self.table.struct_bytes = C.sizeof(TransportTable)
+        self._cb = (_EXCHANGE_FN(self._exchange), _ALLREDUCE_FN(self._allreduce))  # keep alive
+        self.table.exchange, self.table.allreduce_max_u32 = self._cb
 
-    def plane(self, image_id: int, local_z: int):
-        ptr, nbytes = self.engine.image_plane_ptr(image_id, local_z)
-        off = ptr - self._base
-        view = self.arena[off:off + nbytes]
-        dtype, _ = E.IMAGE_DTYPES[image_id]
-        return view.view(self.torch.float32) if dtype == np.float32 else view
+    def _host_view(self, ptr: int, nbytes: int):
+        arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
+        return self.torch.from_numpy(arr)
 
-    def _view(self, ptr: int, nbytes: int, as_float: bool):
-        off = ptr - self._base
-        view = self.arena[off:off + nbytes]
-        return view.view(self.torch.float32) if as_float else view
+    def _exchange(self, _user, ops, count):
+        try:
+            torch, dist = self.torch, self.dist
+            p2p, landings = [], []
+            for i in range(count):
+                x = ops[i]
+                send = bool(x.flags & XFER_SEND)
+                on_device = self.device_memory and not (x.flags & XFER_HOST_MEMORY)
+                if on_device:
+                    host = torch.empty(int(x.bytes), dtype=torch.uint8)
+                    if send:
+                        rc = self._hip.hipMemcpy(host.data_ptr(), x.ptr, int(x.bytes), 2)  # D2H
+                        if rc:
+                            raise RuntimeError(f"hipMemcpy D2H failed ({rc})")
+                    else:
+                        landings.append((host, int(x.ptr), int(x.bytes)))
+                else:
+                    host = self._host_view(int(x.ptr), int(x.bytes))
+                p2p.append(dist.P2POp(dist.isend if send else dist.irecv, host, int(x.peer)))
+            for work in dist.batch_isend_irecv(p2p):
+                work.wait()
+            for host, ptr, nbytes in landings:
+                rc = self._hip.hipMemcpy(ptr, host.data_ptr(), nbytes, 1)  # H2D
+                if rc:
+                    raise RuntimeError(f"hipMemcpy H2D failed ({rc})")
+            return 0
+        except Exception as e:  # never let an exception cross the C frame
+            self.error = e
+            return -3
 
-    def upload(self, image_id: int, array: np.ndarray):
-        self.engine.upload_image(image_id, array)
-
-    def download(self, image_id: int) -> np.ndarray:
-        return self.engine.download_image(image_id)
-
-    def clear_pressures(self):
-        self.engine.run_section("12a_clear_pressures_1")
-        self.engine.run_section("12b_clear_pressures_2")
-
-    # ---- the loop section in explicit form (include/fluid_engine.h: fluid_pressure_loop_*) ----
-    # A "loop buffer" is anything the slabs must exchange boundary planes of.  planes(buf, first, n)
-    # returns n consecutive local planes starting at `first` as one flat tensor (contiguous memory).
-    def max_halo(self) -> int:
-        """Deepest halo this backend can use (planes per exchange = sweeps between exchanges)."""
-        return self.engine.LOOP_MAX_HALO if self.fast else 1
-
-    def loop_begin(self, halo: int):
-        """Returns [(buffer, planes)] to exchange once before the first advance; the newest
-        iterate is then in buffer 0 with `halo` valid ghost planes (after loop_halo_exchanged)."""
-        if self.fast:
-            self.engine.pressure_loop_begin()
-            aux = max(halo - 1, 1)
-            return [(self.engine.LOOP_MASK, aux), (self.engine.LOOP_RHS, aux), (0, halo)]
-        return [(0, 1), (1, 1)]  # the two pressure images themselves
-
-    def loop_halo_exchanged(self, halo: int, first: bool):
-        if self.fast:
-            self.engine.pressure_loop_halo_exchanged(halo, max(halo - 1, 1) if first else 0)
-
-    def loop_max_sweeps(self) -> int:
-        return self.engine.pressure_loop_max_sweeps() if self.fast else 1
-
-    def loop_advance(self, k: int, sweeps: int, keep_mid: bool, part: Optional[str] = None,
-                     interior: Optional[Tuple[int, int]] = None) -> int:
-        """Sweeps k .. k+sweeps-1.  Returns the buffer that now holds the newest iterate.
-        `part` = "edges" / "interior": one of the two launches of a split two-sweep pass; the output
-        planes [interior[0], interior[1]) are the interior (include/fluid_engine.h)."""
-        if self.fast:
-            if part is not None:
-                assert sweeps == 2
-                which = (self.engine.LOOP_PART_EDGES if part == "edges"
-                         else self.engine.LOOP_PART_INTERIOR)
-                return self.engine.pressure_loop_advance_part(keep_mid, which, *interior)
-            return self.engine.pressure_loop_advance(sweeps, keep_mid)
-        assert sweeps == 1 and part is None
-        self.engine.run_pressure_dispatch(1 if k % 2 == 0 else 0)
-        return (k + 1) % 2
-
-    # ---- a halo exchange that runs beside compute: a second stream, ordered by events ----
-    can_overlap = True
-
-    def comm_scope(self):
-        """Context in which the exchange is issued: the communication stream, which first waits for
-        everything launched on the compute stream so far."""
-        torch = self.torch
-        if self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=self.device)
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        self.comm_stream.wait_event(ev)
-        if self.edge_ext is not None:  # ... and on the edge stream (the planes to send come from there)
-            ev2 = torch.cuda.Event()
-            ev2.record(self.edge_ext)
-            self.comm_stream.wait_event(ev2)
-        return torch.cuda.stream(self.comm_stream)
-
-    def comm_mark(self):
-        """Call inside comm_scope() after the exchange has been issued (and stream-waited for)."""
-        ev = self.torch.cuda.Event()
-        ev.record(self.comm_stream)
-        return ev
-
-    def comm_join(self, mark):
-        """Launches on the compute stream (and the edge stream) from here on come after the exchange."""
-        self.stream.wait_event(mark)
-        if self.edge_ext is not None:
-            self.edge_ext.wait_event(mark)
-
-    def loop_end(self):
-        if self.fast:
-            self.engine.pressure_loop_end()
-
-    def planes(self, buf: int, first: int, count: int):
-        if self.fast:
-            ptr, nbytes = self.engine.pressure_loop_plane_ptr(buf, first)
-            return self._view(ptr, nbytes * count, buf != self.engine.LOOP_MASK)
-        ptr, nbytes = self.engine.image_plane_ptr(E.PRESSURES_1 if buf == 0 else E.PRESSURES_2, first)
-        return self._view(ptr, nbytes * count, True)
-
-    def sync(self):
-        self.torch.cuda.synchronize(self.device)
-
-    def halo_written(self, image_id: int):
-        self.engine.notify_ghost_planes_written(image_id)
-
-    def run_section_group(self, first: str, count: int):
-        self.engine.run_section_group(first, count)
-
-    def set_diffuse_mode(self, mode: int):
-        self.engine.set_diffuse_mode(mode)
-
-    # ---- full step on slabs -----------------------------------------------------------------------
-    IMAGE_GHOST = E.FluidEngine.IMAGE_GHOST_PLANES
-
-    def run_section(self, name: str):
-        self.engine.run_section(name)
-
-    def image_planes(self, image_id: int, first: int, count: int):
-        """`count` consecutive local planes of an image as one flat tensor."""
-        ptr, nbytes = self.engine.image_plane_ptr(image_id, first)
-        dtype, _ = E.IMAGE_DTYPES[image_id]
-        return self._view(ptr, nbytes * count, dtype == np.float32)
-
-    def collect_leavers(self):
-        """Particles that left this slab in 14_particles: (uint8 tensor of 32-byte entries, count)."""
-        ptr, n = self.engine.particles_collect_leavers()
-        if n == 0:
-            return self.arena[:0], 0
-        return self._view(ptr, n * self.engine.LEAVER_BYTES, False), n
-
-    def adopt(self, entries, count: int):
-        if count:
-            self.engine.particles_adopt(entries.data_ptr(), count)
-
-    def halo_violation(self) -> bool:
-        return self.engine.slab_halo_violation()
-
-    def download_particles(self) -> np.ndarray:
-        return self.engine.download_particles()
-
-    def upload_particles(self, particles: np.ndarray):
-        self.engine.upload_particles(particles)
-
-    def close(self):
-        self.engine.close()
+    def _allreduce(self, _user, values, count):
+        try:
+            t = self.torch.tensor([int(values[i]) for i in range(count)], dtype=self.torch.int64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            for i in range(count):
+                values[i] = int(t[i])
+            return 0
+        except Exception as e:
+            self.error = e
+            return -3
 
 
-class HostSlabCompute:
-    """CPU stand-in with the same interface, for the multi-process tests: numpy arrays with GW ghost
-    planes per side, the sweep supplied by the caller (the tests pass the CPU oracle).  Not a product
-    path.  Loop buffers: 0..2 working pressures, 3 cell types, 4 divergence."""
+# ---- per-slab compute by callbacks (tests/host_standin.py puts the CPU oracle behind this) -------------
+class CallbackBackend:
+    """fluid_slab_backend filled from a Python object with the methods named below (the calls the driver
+    makes on the engine, see include/fluid_slab.h).  Test infrastructure: the product computes with the
+    HIP engine (SlabDriver without `compute`)."""
 
-    GW = 8
-    TYPES, DIV = 3, 4
-
-    def __init__(self, params: FluidParams, slab: Tuple[int, int], sweep_fn, max_sweeps: int = 2):
-        import torch
-
-        self.torch = torch
-        w, h, _ = params.size
-        self.params = params
-        self.z0, self.dl = slab
-        self.sweep_fn = sweep_fn
-        self.max_sweeps = max_sweeps
-        shape = (self.dl + 2 * self.GW, h, w)
-        self.arr = {
-            E.CELL_TYPES: torch.zeros(shape, dtype=torch.uint8),
-            E.DIVERGENCES: torch.zeros(shape, dtype=torch.float32),
-            E.PRESSURES_1: torch.zeros(shape, dtype=torch.float32),
-            E.PRESSURES_2: torch.zeros(shape, dtype=torch.float32),
-        }
-        self.work = [torch.zeros(shape, dtype=torch.float32) for _ in range(3)]
-        self.cur, self.prev, self.k = 0, -1, 0
-
-    def _owned(self, t):
-        return t[self.GW:self.GW + self.dl]
-
-    def plane(self, image_id: int, local_z: int):
-        return self.arr[image_id][local_z + self.GW].view(-1)
-
-    def upload(self, image_id: int, array: np.ndarray):
-        self._owned(self.arr[image_id])[...] = self.torch.from_numpy(np.ascontiguousarray(array))
-
-    def download(self, image_id: int) -> np.ndarray:
-        return self._owned(self.arr[image_id]).numpy().copy()
-
-    def clear_pressures(self):
-        self._owned(self.arr[E.PRESSURES_1])[...] = float(self.params.pressure_air)
-        self._owned(self.arr[E.PRESSURES_2])[...] = float(self.params.pressure_air)
-
-    def max_halo(self) -> int:
-        return self.GW
-
-    def loop_begin(self, halo: int):
-        self._owned(self.work[0])[...] = self._owned(self.arr[E.PRESSURES_1])
-        self.cur, self.prev, self.k = 0, -1, 0
-        return [(self.TYPES, halo), (self.DIV, max(halo - 1, 1)), (0, halo)]
-
-    def loop_halo_exchanged(self, halo: int, first: bool):
-        pass
-
-    def loop_max_sweeps(self) -> int:
-        return self.max_sweeps
-
-    def _other(self, a, b):
-        return next(i for i in range(3) if i not in (a, b))
-
-    def _sweep(self, src, dst):
-        # one sweep over the slab INCLUDING its ghost planes as if they were cells: with valid data g
-        # planes deep in the ghost region the result is exact g-1 planes deep (and on all owned planes)
-        self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
-                      self.work[src].numpy(), self.work[dst].numpy())
-
-    can_overlap = True
-
-    def comm_scope(self):
-        import contextlib
-
-        return contextlib.nullcontext()
-
-    def comm_mark(self):
-        return None
-
-    def comm_join(self, mark):
-        pass
-
-    def _split_pass(self, keep_mid: bool, part: str, interior):
-        """One launch of a split pass: two sweeps from `cur` into scratch copies, of which only this
-        part's planes are stored — so a part that (wrongly) depended on ghost planes still in flight
-        would show up as a mismatch."""
-        dst = self._other(self.cur, self.cur)
-        mid = self._other(self.cur, dst)
-        t_mid, t_dst = self.work[mid].clone(), self.work[dst].clone()
-        self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
-                      self.work[self.cur].numpy(), t_mid.numpy())
-        self.sweep_fn(self.params, self.arr[E.CELL_TYPES].numpy(), self.arr[E.DIVERGENCES].numpy(),
-                      t_mid.numpy(), t_dst.numpy())
-        n = self.dl + 2 * self.GW
-        a = min(max(interior[0] + self.GW, 0), n)
-        b = min(max(interior[1] + self.GW, a), n)
-        ranges = [(a, b)] if part == "interior" else [(0, a), (b, n)]
-        for lo, hi in ranges:
-            self.work[dst][lo:hi] = t_dst[lo:hi]
-            self.work[mid][lo:hi] = t_mid[lo:hi]
-        if self._part_done is None:
-            self._part_done = part
-            return dst
-        assert self._part_done != part
-        self._part_done = None
-        self.prev = mid if keep_mid else -1
-        self.cur = dst
-        self.k += 2
-        return dst
-
-    _part_done = None
-
-    def loop_advance(self, k: int, sweeps: int, keep_mid: bool, part=None, interior=None):
-        assert k == self.k
-        if part is not None:
-            assert sweeps == 2
-            return self._split_pass(keep_mid, part, interior)
-        assert self._part_done is None
-        if sweeps == 2:
-            dst = self._other(self.cur, self.cur)
-            mid = self._other(self.cur, dst)
-            self._sweep(self.cur, mid)
-            self._sweep(mid, dst)
-            self.prev = mid if keep_mid else -1
-            self.cur = dst
-        else:
-            dst = self._other(self.cur, self.prev if self.prev >= 0 else self.cur)
-            self._sweep(self.cur, dst)
-            self.prev, self.cur = self.cur, dst
-        self.k += sweeps
-        return self.cur
-
-    def loop_end(self):
-        if self.k == 0:
-            return
-        water = self._owned(self.arr[E.CELL_TYPES]) == int(self.params.cell_type_water)
-        even, odd = (self.cur, self.prev) if self.k % 2 == 0 else (self.prev, self.cur)
-        for img, buf in ((E.PRESSURES_1, even), (E.PRESSURES_2, odd)):
-            if buf >= 0:
-                dst = self._owned(self.arr[img])
-                dst[water] = self._owned(self.work[buf])[water]
-
-    def planes(self, buf: int, first: int, count: int):
-        t = self.work[buf] if buf < 3 else self.arr[E.CELL_TYPES if buf == self.TYPES
-                                                     else E.DIVERGENCES]
-        return t[first + self.GW:first + self.GW + count].view(-1)
-
-    def sync(self):
-        pass
-
-    def halo_written(self, image_id: int):
-        pass
-
-    def close(self):
-        pass
-
-
-# ---- the solver ------------------------------------------------------------------------------------------
-class SlabPressureSolver:
-    def __init__(self, size, iterations: int, ctx: DistContext, compute, slab: Tuple[int, int],
-                 transport: str = "direct", halo_depth: int = 8):
-        # halo_depth h: the slabs exchange h boundary planes at a time and then run h sweeps without
-        # communication, recomputing the shrinking ghost region (same bytes on the wire as one plane
-        # per sweep, h times fewer messages and host round trips).  Clipped to what the compute
-        # backend and the slab thickness allow; even, so sweeps can go in pairs.
-        self.halo_depth = halo_depth
-        # run halo exchanges beside the passes that do not need them (solve()): True = split the pass
-        # before and the pass after each exchange, "before" = only the pass before it, False = exchanges
-        # in line.  FLUID_SLAB_OVERLAP=0 / before / 1 forces one; bench.py --gpus N measures all three.
-        env = os.environ.get("FLUID_SLAB_OVERLAP", "1")
-        self.overlap = False if env == "0" else ("before" if env == "before" else True)
-        # transport "direct": the communicator addresses the planes where they live (RCCL on
-        # device memory, gloo on host memory).  "staged": bounce through host tensors — only for
-        # rehearsing the GPU slab path over gloo on a box with a single GPU (tests).
-        self.transport = transport
-        self.size = tuple(size)
-        self.iterations = iterations
-        self.ctx = ctx
+    def __init__(self, compute):
         self.compute = compute
-        self.z_begin, self.z_count = slab
-        self.lo = ctx.rank - 1 if ctx.rank > 0 else None
-        self.hi = ctx.rank + 1 if ctx.rank < ctx.world - 1 else None
-        self._plans = {}
-        self._ops = {}
-        self.exchanges = 0  # halo exchanges performed (diagnostics)
-        self.overlapped = 0  # ... of which started beside a split pass
+        self.error = None
+        self.k = 0
+        self.table = BackendTable()
+        self.table.struct_bytes = C.sizeof(BackendTable)
+        self._keep = []
+        for name, _ in _BACKEND_FIELDS:
+            fn = _BACKEND_FN[name](self._guard(getattr(self, "_" + name)))
+            self._keep.append(fn)
+            setattr(self.table, name, fn)
 
-    @classmethod
-    def create_gpu(cls, size, iterations: int, ctx: DistContext, pressure_kernel: int = 0,
-                   seed: Optional[int] = None, params: Optional[FluidParams] = None):
-        """Full-fluid benchmark scene (scenes.py) on this rank's slab of the global grid."""
-        from . import scenes
+    def _guard(self, f):
+        def call(_user, *args):
+            try:
+                f(*args)
+                return 0
+            except Exception as e:
+                self.error = e
+                return -3
+        return call
 
-        w, h, d = size
-        params = params or default_params(w, h, d, 0)
-        slab = partition_z(d, ctx.world)[ctx.rank]
-        comp = GpuSlabCompute(params, slab, ctx.device, pressure_kernel)
-        self = cls(size, iterations, ctx, comp, slab)
-        shape = (slab[1], h, w)
-        comp.upload(E.CELL_TYPES, scenes.full_fluid_types(shape, slab[0], d))
-        comp.upload(E.DIVERGENCES, scenes.full_fluid_divergence(
-            shape, scenes.SEED_JACOBI if seed is None else seed, slab[0]))
-        self.exchange(E.CELL_TYPES)
+    @staticmethod
+    def _region(t, ptr, nbytes):
+        """t: a flat contiguous torch tensor / numpy array."""
+        if hasattr(t, "data_ptr"):
+            ptr[0], nbytes[0] = t.data_ptr(), t.numel() * t.element_size()
+        else:
+            ptr[0], nbytes[0] = t.ctypes.data, t.nbytes
+
+    def _run_section(self, sid):
+        self.compute.run_section(E.SECTION_NAMES[sid])
+
+    def _run_section_group(self, first, n):
+        self.compute.run_section_group(E.SECTION_NAMES[first], n)
+
+    def _image_planes(self, image, first, count, ptr, nbytes):
+        self._region(self.compute.image_planes(image, first, count), ptr, nbytes)
+
+    def _ghost_planes_written(self, image):
+        self.compute.halo_written(image)
+
+    def _loop_limits(self, max_sweeps, max_halo):
+        max_sweeps[0], max_halo[0] = self.compute.loop_max_sweeps(), self.compute.max_halo()
+
+    def _loop_begin(self, halo, out, count):
+        bufs = self.compute.loop_begin(halo)
+        for i, (which, planes) in enumerate(bufs):
+            out[i].which, out[i].planes = which, planes
+        count[0] = len(bufs)
+
+    def _loop_halo_exchanged(self, halo, first):
+        self.compute.loop_halo_exchanged(halo, bool(first))
+
+    def _loop_advance(self, k, sweeps, keep, part, lo, hi, written):
+        name = {0: None, LOOP_PART_EDGES: "edges", LOOP_PART_INTERIOR: "interior"}[part]
+        written[0] = self.compute.loop_advance(k, sweeps, bool(keep), name, (lo, hi))
+
+    def _loop_end(self):
+        self.compute.loop_end()
+
+    def _loop_planes(self, which, first, count, ptr, nbytes):
+        self._region(self.compute.planes(which, first, count), ptr, nbytes)
+
+    def _slab_status(self, flag):
+        flag[0] = 1 if self.compute.halo_violation() else 0
+
+    def _set_sampler_halo(self, planes):
+        self.compute.set_sampler_halo(planes)
+
+    def _sampler_reach(self, planes):
+        planes[0] = self.compute.sampler_reach()
+
+    def _sampler_wide_begin(self, below, above):
+        self.compute.sampler_wide_begin(below, above)
+
+    def _sampler_wide_planes(self, first, count, ptr, nbytes):
+        self._region(self.compute.sampler_wide_planes(first, count), ptr, nbytes)
+
+    def _run_advect_wide(self, forces):
+        self.compute.run_advect_wide(bool(forces))
+
+    def _migrate_list(self, which, lst, cap):
+        t, n = self.compute.migrate_list(which)
+        p, b = (C.c_void_p * 1)(), (C.c_uint64 * 1)()
+        self._region(t, p, b)
+        lst[0], cap[0] = p[0], n
+
+    def _collect(self, reset, counts, left):
+        (counts[0], counts[1]), left[0] = self.compute.collect(bool(reset))
+
+    def _adopt_received(self, nb, na, fwd):
+        fwd[0], fwd[1] = self.compute.adopt_received(nb, na)
+
+    def _sync(self):
+        self.compute.sync()
+
+
+class SlabError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"fluid slab driver error {code}: {message}")
+        self.code = code
+
+
+class SlabDriver:
+    """One rank of a multi-GPU run (include/fluid_slab.h): construct, attach a transport, then
+    ``run_init()`` once and ``run_step()`` per frame like main.cpp:111 / :172."""
+
+    def __init__(self, params: FluidParams, rank: int, world: int, particle_capacity: int = 0,
+                 pressure_iterations: int = 200, device: int = -1, halo_depth: int = 8,
+                 overlap: Optional[int] = None, grouped: bool = True,
+                 diffuse_mode: int = E.DIFFUSE_REFERENCE_EXACT, sampler_halo: int = 0, compute=None):
+        self._lib = _lib()
+        self._h = C.c_void_p()
+        self.params = params.copy()
+        self.rank, self.world = rank, world
+        self.capacity = particle_capacity
+        self.iterations = pressure_iterations
+        self._blob = (C.c_uint8 * PARAMS_BYTES).from_buffer_copy(params.to_bytes())
+        info = SlabCreateInfo()
+        info.struct_bytes = C.sizeof(SlabCreateInfo)
+        info.rank, info.world, info.device = rank, world, device
+        info.params_blob = C.cast(self._blob, C.c_void_p)
+        info.particle_capacity = particle_capacity
+        info.pressure_iterations = pressure_iterations
+        info.halo_depth = halo_depth
+        info.overlap = -1 if overlap is None else overlap
+        info.section_list = 0 if grouped else 1
+        info.diffuse_mode = diffuse_mode
+        info.sampler_halo = sampler_halo
+        self._backend = CallbackBackend(compute) if compute is not None else None
+        self.compute = compute
+        if self._backend is not None:
+            rc = self._lib.fluid_slab_create_custom(C.byref(self._h), C.byref(info),
+                                                    C.byref(self._backend.table))
+        else:
+            rc = self._lib.fluid_slab_create(C.byref(self._h), C.byref(info))
+        if rc != 0:
+            msg = self._lib.fluid_slab_last_error(None)
+            self._h = C.c_void_p()
+            raise SlabError(rc, msg.decode() if msg else "fluid_slab_create failed")
+        z0, n = C.c_uint32(), C.c_uint32()
+        self._lib.fluid_slab_get_slab(self._h, C.byref(z0), C.byref(n))
+        self.slab = (int(z0.value), int(n.value))
+        self._transport = None
+        self.engine = None
+        if self._backend is None:
+            self.engine = E.FluidEngine.from_handle(self._lib.fluid_slab_engine(self._h), params)
+
+    # -- plumbing -----------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        for holder in (self._backend, self._transport):  # a Python callback raised: that is the cause
+            err = getattr(holder, "error", None)
+            if err is not None:
+                holder.error = None
+                raise err
+        msg = self._lib.fluid_slab_last_error(self._h)
+        raise SlabError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.fluid_slab_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
         return self
 
-    # -- halo exchange ---------------------------------------------------------------------------------
-    def _run_plan(self, key, make_planes, width: int):
-        """Send the first/last `width` owned planes to the lower/upper neighbour, receive their
-        last/first owned planes into the ghost planes.  Grouped point-to-point, both directions at
-        once.  Tensor views and P2POps are built once per buffer and reused (planes never move)."""
-        self._finish_plan(self._start_plan(key, make_planes, width, overlapped=False))
+    def __exit__(self, *exc):
+        self.close()
 
-    def _start_plan(self, key, make_planes, width: int, overlapped: bool):
-        """Issue the exchange; `_finish_plan(handle)` before anything may touch the received planes.
-        overlapped: issue it on the compute backend's communication stream (ordered after what has
-        been launched so far), so that launches made between start and finish run beside it."""
-        import torch.distributed as dist
-
-        if self.ctx.world == 1 and self.transport != "loopback":
-            return None
-        self.exchanges += 1
-        if self.z_count < width:
-            raise RuntimeError(f"slab of {self.z_count} planes is thinner than the halo ({width})")
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = []  # (is_send, flat tensor of `width` planes, peer)
-            n = self.z_count
-            if self.lo is not None:
-                plan.append((True, make_planes(0, width), self.lo))
-                plan.append((False, make_planes(-width, width), self.lo))
-            if self.hi is not None:
-                plan.append((True, make_planes(n - width, width), self.hi))
-                plan.append((False, make_planes(n, width), self.hi))
-            self._plans[key] = plan
-        scope = self.compute.comm_scope() if overlapped else None
-        if scope is not None:
-            scope.__enter__()
-        try:
-            if self.transport == "staged":
-                # through host tensors, synchronously (t.cpu() waits for the current stream, which inside
-                # the scope is the communication stream, ordered after the launches that produce the
-                # planes): rehearses the schedule of the GPU path over gloo on a box with one GPU
-                staged = [(snd, t.cpu() if snd else t.new_empty(t.shape, device="cpu"), t, peer)
-                          for snd, t, peer in plan]
-                ops = [dist.P2POp(dist.isend if snd else dist.irecv, h, peer)
-                       for snd, h, _, peer in staged]
-                for work in dist.batch_isend_irecv(ops):
-                    work.wait()
-                for snd, h, t, _ in staged:
-                    if not snd:
-                        t.copy_(h)
-                if not overlapped:
-                    return None
-                return ("overlapped", [], self.compute.comm_mark())
-            if self.transport == "loopback":
-                # single-process rehearsal of one rank's work (tools/slab_rank_sim.py): every receive
-                # is filled by a device copy of a send buffer of the same size; no communicator
-                sends = [t for snd, t, _ in plan if snd]
-                recvs = [t for snd, t, _ in plan if not snd]
-                for i, r in enumerate(recvs):
-                    r.copy_(sends[(i + 1) % len(sends)])
-                works = []
-            else:
-                ops = self._ops.get(key)
-                if ops is None:
-                    ops = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer)
-                           for snd, t, peer in plan]
-                    self._ops[key] = ops
-                works = dist.batch_isend_irecv(ops)
-            if not overlapped:
-                return ("works", works)
-            if self.ctx.backend == "nccl":
-                # stream-level wait (the host does not block): the communication stream now ends
-                # with the exchange, and the mark below is what the compute stream joins on
-                for work in works:
-                    work.wait()
-                works = []
-            return ("overlapped", works, self.compute.comm_mark())
-        finally:
-            if scope is not None:
-                scope.__exit__(None, None, None)
-
-    def _finish_plan(self, handle):
-        if handle is None:
-            return
-        for work in handle[1]:
-            work.wait()
-        if handle[0] == "overlapped":
-            self.compute.comm_join(handle[2])
-
-    def exchange(self, image_id: int):
-        """One-plane halo exchange of an image (cell types at set-up)."""
-        self._run_plan(("img", image_id), lambda z, n: self.compute.plane(image_id, z), 1)
-        self.compute.halo_written(image_id)  # derived data (the neighbour mask) is rebuilt
-
-    def exchange_loop_buffer(self, buf: int, width: int):
-        """Halo exchange of a buffer of the running loop, `width` planes deep."""
-        self._run_plan(("loop", buf, width), lambda z, n: self.compute.planes(buf, z, n), width)
-
-    # -- the loop section ---------------------------------------------------------------------------------
-    def clear_pressures(self):
-        self.compute.clear_pressures()
-
-    def effective_halo(self) -> int:
-        # every rank must come to the same depth: limit by the thinnest slab of the partition
-        thinnest = min(n for _, n in partition_z(self.size[2], self.ctx.world))
-        h = min(self.halo_depth, self.compute.max_halo(), thinnest)
-        if self.compute.loop_max_sweeps() >= 2 and h >= 2:
-            h -= h % 2
-        return max(h, 1)
-
-    def solve(self, iterations: Optional[int] = None):
-        """FlowLoopPushConstantSection semantics: dispatch k maps iterate k to iterate
-        k+1; after N dispatches PRESSURES_1 holds the last even iterate, PRESSURES_2 the last odd one.
-        Every sweep consumes one valid ghost plane per side; when fewer are left than the next
-        launch needs (2 for a two-sweeps-per-pass launch), `h` boundary planes of the newest iterate
-        are exchanged with the two Z-neighbours.
-
-        Overlap (self.overlap, h >= 4, slabs thicker than 2h): the pass before an exchange is split —
-        the h planes per face that will be sent are computed first, the exchange starts on the
-        communication stream, the planes in between follow —, and so is the pass after it: the
-        output planes that depend on owned planes only are computed while the exchange is in flight,
-        the rest once it has landed.  Same arithmetic, same iterates."""
-        n = self.iterations if iterations is None else iterations
-        c = self.compute
-        h = self.effective_halo()
-        for buf, width in c.loop_begin(h):
-            self.exchange_loop_buffer(buf, width)
-        c.loop_halo_exchanged(h, True)
-        valid = h          # valid ghost planes of the newest iterate
-        cur = 0            # buffer holding it
-        pair = c.loop_max_sweeps() >= 2 and h >= 2
-        thinnest = min(m for _, m in partition_z(self.size[2], self.ctx.world))
-        split = (self.overlap and pair and h >= 4 and thinnest > 2 * h
-                 and getattr(c, "can_overlap", False)
-                 and (self.ctx.world > 1 or self.transport == "loopback"))
-        big = 1 << 30
-        dl = self.z_count
-        # interior of the pass before an exchange / of the pass after it (local output planes)
-        before = (h if self.lo is not None else -big, dl - h if self.hi is not None else big)
-        after = (2 if self.lo is not None else -big, dl - 2 if self.hi is not None else big)
-        pending = None     # exchange in flight: finish before launching anything that reads ghosts
-        k = 0
-        while k < n:
-            sweeps = 2 if (pair and n - k >= 2) else 1
-            keep = sweeps == 2 and n - k == 2
-            if pending is None and valid < sweeps:
-                self.exchange_loop_buffer(cur, h)
-                c.loop_halo_exchanged(h, False)
-                valid = h
-            left = n - k - sweeps
-            next_sweeps = 2 if (pair and left >= 2) else min(left, 1)
-            valid_after = valid - 2 if sweeps == 2 else 0
-            if pending is not None and self.overlap == "before":
-                # half the overlap: only the pass before the exchange was split; wait, then a whole pass
-                self._finish_plan(pending)
-                pending = None
-                cur = c.loop_advance(k, sweeps, keep)
-            elif pending is not None:
-                # first pass after the exchange started: valid == h here (reported at the start)
-                c.loop_advance(k, 2, keep, "interior", after)
-                self._finish_plan(pending)
-                pending = None
-                cur = c.loop_advance(k, 2, keep, "edges", after)
-            elif split and sweeps == 2 and next_sweeps == 2 and valid_after < 2:
-                dst = c.loop_advance(k, 2, keep, "edges", before)
-                self.overlapped += 1
-                pending = self._start_plan(("loop", dst, h),
-                                           lambda z, m, b=dst: c.planes(b, z, m), h, overlapped=True)
-                cur = c.loop_advance(k, 2, keep, "interior", before)
-                assert cur == dst
-                c.loop_halo_exchanged(h, False)  # started; the next pass orders itself behind it
-                valid_after = h
-            else:
-                cur = c.loop_advance(k, sweeps, keep)
-            valid = valid_after
-            k += sweeps
-        assert pending is None
-        c.loop_end()
-
-    def step(self):
-        self.clear_pressures()
-        self.solve()
-
-    # -- measurement -----------------------------------------------------------------------------------------
-    def benchmark(self, steps: int, warmup: int) -> dict:
+    # -- transport ------------------------------------------------------------------------------------
+    def attach_rccl(self):
+        """RCCL point-to-point between the GPUs: rank 0 makes the unique id, the torch.distributed group
+        (any backend) carries it to the others, every rank initialises its communicator."""
         import torch
         import torch.distributed as dist
 
-        probe = self._probe_overlap()
-        for _ in range(warmup):
-            self.step()
-        eng = getattr(self.compute, "engine", None)
-        self.compute.sync()
-        dist.barrier()
-        self.compute.sync()
-        if eng is not None:
-            eng.enable_timing(True)
-            eng.reset_timing()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
-        self.compute.sync()
-        dist.barrier()
-        self.compute.sync()
-        wall = time.perf_counter() - t0
-        t = torch.tensor([wall], dtype=torch.float64, device=self.ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out = {"wall_s": float(t.item()),
-               "local_cells": self.size[0] * self.size[1] * self.z_count,
-               "halo_overlap": probe}
-        if eng is not None:
-            ms, calls = eng.section_time_ms("12_solve_pressure")
-            eng.enable_timing(False)
-            k = torch.tensor([ms / max(calls, 1)], dtype=torch.float64, device=self.ctx.device)
-            dist.all_reduce(k, op=dist.ReduceOp.MAX)
-            out["kernel_ms_per_sweep"] = float(k.item())
-            out["exchange_ms_per_sweep"] = max(
-                0.0, 1e3 * out["wall_s"] / (steps * self.iterations) - out["kernel_ms_per_sweep"])
-        return out
+        buf = (C.c_uint8 * RCCL_ID_BYTES)()
+        if self.rank == 0:
+            rc = self._lib.fluid_slab_rccl_unique_id(buf)
+            if rc != 0:
+                msg = self._lib.fluid_slab_last_error(None)
+                raise SlabError(rc, msg.decode() if msg else "")
+        if self.world > 1:
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            buf = (C.c_uint8 * RCCL_ID_BYTES)(*t.cpu().tolist())
+        self._check(self._lib.fluid_slab_attach_rccl(self._h, buf))
 
-    def _probe_overlap(self) -> dict:
-        """Untimed, before the warm-up: one step of the loop with the exchanges issued in line and one
-        with the split-pass overlap (solve()), each after a step of its own to set up streams and
-        communicators; every rank adopts the faster schedule (MAX over ranks).  Whether hiding an
-        8-MiB exchange is worth two extra launches per exchange depends on the link, so it is measured
-        where it runs."""
-        import torch
-        import torch.distributed as dist
+    def attach_torch_transport(self, device_memory: bool = False):
+        """The C++ schedule over torch.distributed point-to-point (gloo) instead of RCCL."""
+        self._transport = TorchDistTransport(device_memory)
+        self._check(self._lib.fluid_slab_attach_transport(self._h, C.byref(self._transport.table)))
 
-        if not self.overlap or self.ctx.world == 1 or "FLUID_SLAB_OVERLAP" in os.environ:
-            return {"used": self.overlap if self.ctx.world > 1 else False, "probed": False}
-        times = {}
-        for mode in (False, "before", True):
-            self.overlap = mode
-            self.step()
-            self.compute.sync()
-            dist.barrier()
-            t0 = time.perf_counter()
-            self.step()
-            self.compute.sync()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            times[mode] = float(t.item())
-        self.overlap = min(times, key=times.get)  # the same on every rank: the times are the all-reduced MAX
-        return {"used": self.overlap if self.overlap else False, "probed": True,
-                "step_ms_inline": 1e3 * times[False], "step_ms_overlap_before": 1e3 * times["before"],
-                "step_ms_overlapped": 1e3 * times[True]}
+    def attach_loopback(self, has_lower: bool = True, has_upper: bool = True):
+        self._check(self._lib.fluid_slab_attach_loopback(self._h, int(has_lower), int(has_upper)))
 
-    def gather_pressures(self):
-        """Rank 0 gets the global PRESSURES_1 / PRESSURES_2 arrays (tests)."""
-        import torch
-        import torch.distributed as dist
-
-        res = []
-        for img in (E.PRESSURES_1, E.PRESSURES_2):
-            local = torch.from_numpy(self.compute.download(img))
-            parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
-            dist.gather_object(local.numpy(), parts, dst=0)
-            res.append(np.concatenate(parts, axis=0) if self.ctx.rank == 0 else None)
-        return res
-
-    def close(self):
-        self.compute.close()
-
-
-# ---- the whole simulation step on Z slabs ---------------------------------------------------------------
-class SlabSimulation:
-    """SimulationInitializationSections / SimulationStepSections (fluid_flow_sections.h:136-338) with
-    the grid cut into Z slabs, one rank per slab: the reference's section order, plus the ghost-plane
-    exchanges the stencils and the velocity sampler need and the hand-over of particles that cross a
-    slab face (include/fluid_engine.h, "Z-slab contexts, full step").  Results equal the single-GPU
-    (and the oracle's) step bit for bit as long as no sample reaches further than the ghost planes
-    (checked every step)."""
-
-    def __init__(self, params: FluidParams, particle_capacity: int, iterations: int, ctx: DistContext,
-                 compute=None, transport: str = "direct", halo_depth: int = 8, grouped: bool = True,
-                 overlap: Optional[bool] = None, diffuse_mode: int = E.DIFFUSE_REFERENCE_EXACT):
-        # grouped: 04+05, 07+08 and 09+10+11 as single passes (include/fluid_engine.h:
-        # fluid_run_section_group); 09+10+11 needs fluid_size.x % 4 == 0
-        self.grouped = grouped
-        # E.DIFFUSE_INTENDED: 09 is the 7-point diffusion the shader meant (SURVEY.md F1), which needs a
-        # ghost plane of VELOCITIES_2 per side and runs 09, 10, 11 one by one
-        self.diffuse_mode = diffuse_mode
-        self.params = params
-        self.ctx = ctx
-        self.size = params.size
-        self.capacity = particle_capacity
-        slab = partition_z(self.size[2], ctx.world)[ctx.rank]
-        self.slab = slab
-        self.compute = compute or GpuSlabCompute(params, slab, ctx.device,
-                                                 particle_capacity=particle_capacity,
-                                                 pressure_iterations=iterations)
-        if diffuse_mode != E.DIFFUSE_REFERENCE_EXACT:
-            self.compute.set_diffuse_mode(diffuse_mode)
-        self.pressure = SlabPressureSolver(self.size, iterations, ctx, self.compute, slab,
-                                           transport=transport, halo_depth=halo_depth)
-        if overlap is not None:  # else SlabPressureSolver's default (FLUID_SLAB_OVERLAP)
-            self.pressure.overlap = overlap
-        self.transport = transport
-        self.ghost = min(self.compute.IMAGE_GHOST, min(n for _, n in partition_z(self.size[2],
-                                                                                  ctx.world)))
-        self.migrated = 0  # particles handed over so far (diagnostics)
-
-    # -- halo exchange of an image, `width` planes deep (reuses the solver's plan machinery)
-    def exchange_image(self, image_id: int, width: int):
-        self.pressure._run_plan(("image", image_id, width),
-                                lambda z, n: self.compute.image_planes(image_id, z, n), width)
-        self.compute.halo_written(image_id)
-
+    # -- the frame loop -------------------------------------------------------------------------------
     def run_init(self):
-        for name in ("init_clear_velocities_1", "init_clear_cell_types", "00_init_particles"):
-            self.compute.run_section(name)
-        # cleared images are uniform, but their value need not be the ghost planes' zero
-        self.exchange_image(E.CELL_TYPES, 1)
-        self.exchange_image(E.VELOCITIES_1, self.ghost)
+        self._check(self._lib.fluid_slab_run_init(self._h))
 
     def run_step(self):
-        c, x = self.compute, self.exchange_image
-        c.run_section("01a_clear_particle_densities")
-        c.run_section("01_update_densities")          # owned particles only, into owned planes
-        c.run_section("02_update_water")
-        x(E.NEW_CELL_TYPES, 1)                         # 03 looks at z-1 / z+1
-        c.run_section("03_update_air")
-        x(E.NEW_CELL_TYPES, 1)                         # 05 reads the final new types at z-1
-        if self.grouped:                               # old types / V1 at z+-1: still current
-            c.run_section_group("04_compute_extrapolated_velocities", 2)
-        else:
-            c.run_section("04_compute_extrapolated_velocities")
-            c.run_section("05_set_extrapolated_velocities")
-        x(E.VELOCITIES_1, self.ghost)                  # 07 samples V1 around each cell
-        c.run_section("06_update_cell_types")          # carries one ghost plane per side along
-        if self.grouped:
-            c.run_section_group("07_advect", 2)
-        else:
-            c.run_section("07_advect")
-            c.run_section("08_forces")
-        intended = self.diffuse_mode == E.DIFFUSE_INTENDED
-        if self.grouped and self.size[0] % 4 == 0 and not intended:
-            x(E.VELOCITIES_2, 1)                       # 11, on what 10 makes of V2 at z+1
-            c.run_section_group("09_diffuse", 3)
-        else:
-            if intended:
-                x(E.VELOCITIES_2, 1)                   # the diffusion stencil reads V2 at z-1, z+1
-            c.run_section("09_diffuse")
-            c.run_section("10_solids")
-            x(E.VELOCITIES_1, 1)                       # 11 reads V1 at z+1
-            c.run_section("11_compute_divergence")
-        self.pressure.step()                           # 12a, 12b, the 12_solve_pressure loop
-        x(E.PRESSURES_2, 1)                            # 13 reads P2 at z-1
-        c.run_section("13_fix_divergence")
-        x(E.VELOCITIES_1, self.ghost)                  # 14 samples V1; 04 of the next step reads z+-1
-        c.run_section("14_particles")
-        self.migrate_particles()
-        if c.halo_violation():
-            raise RuntimeError("a velocity sample reached beyond the ghost planes of this slab "
-                               f"({self.ghost} planes): the fluid moves too fast for the slab halo")
+        self._check(self._lib.fluid_slab_run_step(self._h))
 
-    # -- particles that crossed a slab face change owner
-    def migrate_particles(self):
-        import torch
-        import torch.distributed as dist
+    def pressure_step(self):
+        """12a, 12b and the 12_solve_pressure loop section."""
+        self._check(self._lib.fluid_slab_pressure_step(self._h))
 
-        if self.ctx.world == 1 or self.capacity == 0:
-            return
-        entries, n = self.compute.collect_leavers()
-        staged = self.transport == "staged" or self.ctx.backend == "gloo"
-        dev = torch.device("cpu") if staged else self.ctx.device
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.ctx.world)]
-        dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
-        counts = [int(t.item()) for t in counts]
-        most = max(counts)
-        if most == 0:
-            return
-        width = most * E.FluidEngine.LEAVER_BYTES
-        send = torch.zeros(width, dtype=torch.uint8, device=dev)
-        if n:
-            send[:n * E.FluidEngine.LEAVER_BYTES] = entries.to(dev)
-        gathered = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(self.ctx.world)]
-        dist.all_gather(gathered, send)
-        for r, cnt in enumerate(counts):
-            if cnt and r != self.ctx.rank:
-                self.compute.adopt(gathered[r].to(self.ctx.device) if staged else gathered[r], cnt)
-        self.migrated += sum(counts)
-        self.compute.sync()  # the gathered buffers are released when this returns
+    def solve(self, iterations: int = 0):
+        self._check(self._lib.fluid_slab_solve(self._h, iterations))
 
-    # -- global state in (checkpoint restore): every rank passes the same global array
+    def exchange_image(self, image_id: int, planes: int = 1):
+        self._check(self._lib.fluid_slab_exchange_image(self._h, image_id, planes))
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.fluid_slab_set_option(self._h, option, value))
+
+    def stat(self, which: int) -> int:
+        v = C.c_uint64(0)
+        self._check(self._lib.fluid_slab_get_stat(self._h, which, C.byref(v)))
+        return int(v.value)
+
+    @property
+    def image_ghost(self) -> int:
+        return min(E.FluidEngine.IMAGE_GHOST_PLANES, self.params.size[2] // self.world)
+
+    # -- this rank's part of global arrays (tests, checkpoints, scenes) -----------------------------------
+    def _store(self):
+        return self.engine if self.engine is not None else self.compute
+
     def upload_image_global(self, image_id: int, array: np.ndarray):
+        """Every rank passes the same global array; the slab keeps its planes and fetches its ghosts."""
         z0, n = self.slab
-        self.compute.upload(image_id, np.ascontiguousarray(array[z0:z0 + n]))
-        self.exchange_image(image_id, self.ghost)
+        self.upload_image(image_id, np.ascontiguousarray(array[z0:z0 + n]))
+
+    def upload_image(self, image_id: int, local: np.ndarray):
+        st = self._store()
+        (st.upload_image if self.engine is not None else st.upload)(image_id, local)
+        self.exchange_image(image_id, self.image_ghost)
+
+    def download_image(self, image_id: int) -> np.ndarray:
+        st = self._store()
+        return (st.download_image if self.engine is not None else st.download)(image_id)
 
     def upload_particles_global(self, particles: np.ndarray):
-        self.compute.upload_particles(particles)  # the backend keeps the slots this slab owns
+        self._store().upload_particles(particles)  # the backend keeps the slots this slab owns
 
-    # -- global views (tests, checkpoints): rank 0 gets the arrays, the others None
     def gather_image(self, image_id: int):
+        """Rank 0 gets the global array, the others None."""
         import torch.distributed as dist
 
-        local = self.compute.download(image_id)
-        parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
+        local = self.download_image(image_id)
+        if self.world == 1:
+            return local
+        parts = [None] * self.world if self.rank == 0 else None
         dist.gather_object(local, parts, dst=0)
-        return np.concatenate(parts, axis=0) if self.ctx.rank == 0 else None
+        return np.concatenate(parts, axis=0) if self.rank == 0 else None
 
     def gather_particles(self):
         import torch.distributed as dist
 
-        local = self.compute.download_particles()
-        parts = [None] * self.ctx.world if self.ctx.rank == 0 else None
+        local = self._store().download_particles()
+        if self.world == 1:
+            return local
+        parts = [None] * self.world if self.rank == 0 else None
         dist.gather_object(local, parts, dst=0)
-        if self.ctx.rank != 0:
+        if self.rank != 0:
             return None
         out = np.zeros_like(parts[0])
         owners = np.zeros(out.shape[0], np.int32)
@@ -879,5 +544,98 @@ class SlabSimulation:
             raise RuntimeError(f"{int(np.sum(owners != 1))} particle slots do not have exactly one owner")
         return out
 
-    def close(self):
-        self.compute.close()
+    # -- measurement (bench.py --gpus N) ------------------------------------------------------------------
+    @classmethod
+    def create_full_fluid(cls, size, iterations: int, ctx: DistContext, seed: Optional[int] = None,
+                          **kw) -> "SlabDriver":
+        """The Jacobi benchmark scene (scenes.py) on this rank's slab of the global grid, RCCL attached."""
+        from . import scenes
+
+        w, h, d = size
+        drv = cls(default_params(w, h, d, 0), ctx.rank, ctx.world, pressure_iterations=iterations,
+                  device=ctx.device.index if ctx.device.index is not None else -1, **kw)
+        if ctx.world > 1:
+            drv.attach_rccl()
+        z0, n = drv.slab
+        shape = (n, h, w)
+        drv.upload_image(E.CELL_TYPES, scenes.full_fluid_types(shape, z0, d))
+        drv.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence(
+            shape, scenes.SEED_JACOBI if seed is None else seed, z0))
+        return drv
+
+    def benchmark(self, steps: int, warmup: int, step=None) -> dict:
+        """`steps` timed calls of `step` (default: pressure_step) between barriers; MAX over the ranks."""
+        import torch
+        import torch.distributed as dist
+
+        step = step or self.pressure_step
+        multi = self.world > 1 and dist.is_initialized()
+        probe = self._probe_overlap(step) if step == self.pressure_step else {"probed": False}
+
+        def fence():
+            self._store().sync()
+            if multi:
+                dist.barrier()
+                self._store().sync()
+
+        for _ in range(warmup):
+            step()
+        fence()
+        if self.engine is not None:
+            self.engine.enable_timing(True)
+            self.engine.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        wall = time.perf_counter() - t0
+        ms, calls = 0.0, 0
+        if self.engine is not None:
+            ms, calls = self.engine.section_time_ms("12_solve_pressure")
+            self.engine.enable_timing(False)
+        vals = torch.tensor([wall, ms / max(calls, 1)], dtype=torch.float64)
+        if multi:
+            if dist.get_backend() == "nccl":
+                vals = vals.cuda()
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        wall, kernel = (float(v) for v in vals.cpu())
+        w, h, _ = self.params.size
+        return {"wall_s": wall, "local_cells": w * h * self.slab[1], "halo_overlap": probe,
+                "kernel_ms_per_sweep": kernel,
+                "exchange_ms_per_sweep": max(0.0, 1e3 * wall / (steps * self.iterations) - kernel)}
+
+    def _probe_overlap(self, step) -> dict:
+        """Untimed, before the warm-up: one step with the exchanges of the Jacobi loop in line, one with
+        only the pass before each exchange split and one with both passes split, each after a step of
+        its own; every rank adopts the fastest schedule (the times are MAX over the ranks, so all agree).
+        Whether hiding an 8-MiB exchange is worth two extra launches per exchange depends on the link,
+        so it is measured where it runs.  FLUID_SLAB_OVERLAP=0 / before / 1 forces a schedule."""
+        import torch
+        import torch.distributed as dist
+
+        env = os.environ.get("FLUID_SLAB_OVERLAP")
+        if env is not None:
+            mode = {"0": OVERLAP_NONE, "before": OVERLAP_BEFORE}.get(env, OVERLAP_BOTH)
+            self.set_option(OPT_OVERLAP, mode)
+            return {"used": mode, "probed": False}
+        if self.world == 1 or not dist.is_initialized():
+            return {"used": OVERLAP_NONE, "probed": False}
+        times = {}
+        for mode in (OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH):
+            self.set_option(OPT_OVERLAP, mode)
+            step()
+            self._store().sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            step()
+            self._store().sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times[mode] = float(t.cpu()[0])
+        best = min(times, key=times.get)
+        self.set_option(OPT_OVERLAP, best)
+        return {"used": best, "probed": True, "step_ms_inline": 1e3 * times[OVERLAP_NONE],
+                "step_ms_overlap_before": 1e3 * times[OVERLAP_BEFORE],
+                "step_ms_overlapped": 1e3 * times[OVERLAP_BOTH]}
