@@ -285,8 +285,7 @@ def slab_full_step_bench(size, iters, steps, dist_ctx, overlap=None):
 
     p, cap = fluid_amd.dam_break_params(*size)
     sim = S.SlabDriver(p, dist_ctx.rank, dist_ctx.world, particle_capacity=cap, pressure_iterations=iters,
-                       device=dist_ctx.device.index if dist_ctx.device.index is not None else -1,
-                       overlap=overlap)
+                       device=dist_ctx.device, overlap=overlap)
     if dist_ctx.world > 1:
         sim.attach_rccl()
     sim.run_init()

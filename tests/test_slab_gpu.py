@@ -173,7 +173,7 @@ def test_c5_slab_1024x1024x64_equals_the_whole_grid_run_and_an_oracle_window():
     rank, world = 3, 8
     p = fluid_amd.default_params(w, h, d, 0)
     t, div = c5_scene((d, h, w))
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL("libamdhip64.so.7")  # by soname: the runtime the engine library is bound to
     hip.hipMemcpy.restype = C.c_int
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 

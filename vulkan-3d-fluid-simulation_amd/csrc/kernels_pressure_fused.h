@@ -86,18 +86,30 @@ __device__ __forceinline__ float canon_num(float b, float qxp, float qyp, float 
     s = s - qzm;
     return -s;
 }
-// the four quotients of a lane: n / aii, aii = bytes of m
-__device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const FLUID_LDS char* table) {
+// The (a, r) pairs of the four cells of a lane, from the LDS table.  Issued BEFORE the plane step's barrier
+// (the mask word is known by then), so that the reads are in flight while the wave waits there instead of
+// forming a second and third LDS round trip behind the neighbour rows.
+struct DivPairs {
+    float2 c[4];
+};
+__device__ __forceinline__ DivPairs div_pairs(uint32_t m, const FLUID_LDS char* table) {
+    const uint32_t m8 = m << 3;  // byte i of m8 = 8 * (mask byte i) = offset of its table entry
+    DivPairs d;
+    d.c[0] = lds_ld2(table, m8 & 0xFFu);
+    d.c[1] = lds_ld2(table, (m8 >> 8) & 0xFFu);
+    d.c[2] = lds_ld2(table, (m8 >> 16) & 0xFFu);
+    d.c[3] = lds_ld2(table, m8 >> 24);
+    return d;
+}
+// the four quotients of a lane: n / aii, aii = bytes of m, (aii, RN(1 / aii)) = d
+__device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const DivPairs& d) {
     const float tiny = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
     float4 o;
     if (__builtin_amdgcn_ballot_w64(tiny < 0x1p-90f) == 0ull) {
-        const uint32_t m8 = m << 3;  // byte i of m8 = 8 * (mask byte i) = offset of its table entry
-        const float2 t0 = lds_ld2(table, m8 & 0xFFu), t1 = lds_ld2(table, (m8 >> 8) & 0xFFu);
-        const float2 t2 = lds_ld2(table, (m8 >> 16) & 0xFFu), t3 = lds_ld2(table, m8 >> 24);
-        o.x = div_small_int(n.x, t0);
-        o.y = div_small_int(n.y, t1);
-        o.z = div_small_int(n.z, t2);
-        o.w = div_small_int(n.w, t3);
+        o.x = div_small_int(n.x, d.c[0]);
+        o.y = div_small_int(n.y, d.c[1]);
+        o.z = div_small_int(n.z, d.c[2]);
+        o.w = div_small_int(n.w, d.c[3]);
     } else {
         o.x = n.x / (float)(m & 0xFFu);
         o.y = n.y / (float)((m >> 8) & 0xFFu);
@@ -106,6 +118,33 @@ __device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const FLUID_L
     }
     return o;
 }
+
+// Dev build only (make trace: -DFLUID_FUSED_TRACE): where the cycles of a plane step go.  Every wavefront
+// stamps s_memtime at six points of the step and sums the five phases over its march; wavefront w of the
+// first 64 workgroups stores its sums in g_fused_trace (tools/fused_trace.py reads them).  Not compiled into
+// the product library.
+#ifdef FLUID_FUSED_TRACE
+constexpr int FUSED_TRACE_PHASES = 6;
+__device__ unsigned long long g_fused_trace[64 * 16 * (FUSED_TRACE_PHASES + 1)];
+struct FusedTrace {
+    unsigned long long sum[FUSED_TRACE_PHASES], last;
+    unsigned steps;
+};
+#define FLUID_TRACE_ARG , FusedTrace& ftr
+#define FLUID_TRACE_PASS , ftr
+#define FT_BEGIN() ftr.last = __builtin_amdgcn_s_memtime()
+#define FT(i)                                                        \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        ftr.sum[i] += t_ - ftr.last;                                 \
+        ftr.last = t_;                                               \
+    } while (0)
+#else
+#define FLUID_TRACE_ARG
+#define FLUID_TRACE_PASS
+#define FT_BEGIN()
+#define FT(i)
+#endif
 
 constexpr int FUSED_WAVES = 16;
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
@@ -152,10 +191,13 @@ struct FusedRange {
 //   h[2]  halo row    : slot i&1 = plane zc; the other receives plane zc+1   (halo wavefronts only)
 //   padv[4] (windowed launches) : iterate j at the column just outside the window, slots (i, i+1) =
 //                                  planes zc-1, zc; slot i+2 receives plane zc+1
+//   dv[2] (a, 1/a) pairs : slot i&1 = of the mask word of plane zc (stage 1 of this step), fetched before this
+//                          step's barrier; the other slot = of plane zc-1, fetched a step ago (stage 2)
 struct FusedState {
     float4 j[4], s[4], b[4], h[2];
     uint32_t m[4];
     float padv[4];
+    DivPairs dv[2];
 };
 
 template <int NT>
@@ -216,7 +258,7 @@ struct FusedCtx {
 
 // One plane step: I = ring phase (k mod 4), zc = plane of iterate j+1 formed in this step.
 template <int NT, int I, bool WIN>
-__device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st, int zc) {
+__device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st, int zc FLUID_TRACE_ARG) {
     constexpr int R = FusedCtx<NT>::R;
     constexpr int buf = I & 1;
     float4& jm = st.j[I & 3];
@@ -228,6 +270,7 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
     const float4 b_m = st.b[(I + 1) & 3], b_c = st.b[(I + 2) & 3];
     const uint32_t m_m = st.m[(I + 1) & 3];
 
+    FT_BEGIN();
     // ---- loads the next step needs (raw; fixed up at the end of this step)
     const int64_t o1 = c.j_off(zc + 1), o2 = c.j_off(zc + 2), a1 = c.m_off(zc + 1);
     st.j[(I + 3) & 3] = ld_f4(c.pin + o2, c.boff);
@@ -237,6 +280,23 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
     if (WIN)
         st.padv[(I + 2) & 3] =
             *reinterpret_cast<const float*>(reinterpret_cast<const char*>(c.pin + o1) + c.boff_pad);
+
+    // ---- what the previous step loaded, fixed up (only wavefronts / planes on the grid boundary do
+    // anything here; those loads have had a whole step to land): known BEFORE the barrier, so the
+    // decisions and the table look-ups that depend on the mask word are taken off the path behind it
+    jn = c.fix_j(jn, c.row_in, zc + 1);
+    const float4 hc = c.fix_j(st.h[I & 1], c.halo_in, zc);
+    const uint32_t m_c = c.fix_m(st.m[(I + 2) & 3], zc);
+    st.m[(I + 2) & 3] = m_c;
+    const int zo = zc - 1;
+    const bool do1 = __builtin_amdgcn_ballot_w64(mask_any_water(m_c)) != 0ull;            // wave-uniform
+    const bool wet = c.is_out_row && mask_any_water(m_m);
+    const bool do2 = zo >= c.zb && zo < c.ze && c.rr >= 1 && c.rr <= R - 2 &&            // wave-uniform
+                     __builtin_amdgcn_ballot_w64(wet) != 0ull;
+    FT(0);  // issue of the loads + wait for the previous step's
+    if (do1) st.dv[I & 1] = div_pairs(m_c, c.divtab);  // stage 2 of the next step uses them again
+    const DivPairs& d_c = st.dv[I & 1];
+    const DivPairs& d_m = st.dv[(I + 1) & 1];
 
     // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
     FLUID_LDS float* jrow = c.row_ptr(buf, 0, c.rr);
@@ -250,63 +310,67 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st
             srow[c.pad_x] = c.fix_pad(st.padv[I & 3], zc - 1);
         }
     }
+    FT(1);  // publish
     __syncthreads();
+    FT(2);  // barrier
 
-    // ---- fix up what the previous step loaded (only wavefronts / planes on the grid boundary do
-    // anything here; by now those loads have had a whole step to land)
-    jn = c.fix_j(jn, c.row_in, zc + 1);
-    const float4 hc = c.fix_j(st.h[I & 1], c.halo_in, zc);
-    const uint32_t m_c = c.fix_m(st.m[(I + 2) & 3], zc);
-    st.m[(I + 2) & 3] = m_c;
+    // ---- the neighbour rows of both stages in ONE round trip to LDS
+    float4 jym = hc, jyp = hc, sym = s_m, syp = s_m;
+    float je = 0.f, se = 0.f;
+    if (do1) {
+        if (!c.halo_lo) jym = lds_ld4(c.row_ptr(buf, 0, c.rr - 1) + c.x0);
+        if (!c.halo_hi) jyp = lds_ld4(c.row_ptr(buf, 0, c.rr + 1) + c.x0);
+        je = jrow[c.xe];
+    }
+    if (do2) {
+        sym = lds_ld4(c.row_ptr(buf, 1, c.rr - 1) + c.x0);
+        syp = lds_ld4(c.row_ptr(buf, 1, c.rr + 1) + c.x0);
+        se = srow[c.xe];
+    }
 
     // ---- stage 1: iterate j+1 at plane zc for this row
     s_c = jc;  // non-water (and out-of-grid) cells keep their constant
-    if (__builtin_amdgcn_ballot_w64(mask_any_water(m_c)) != 0ull) {
-        const float4 ym = c.halo_lo ? hc : lds_ld4(c.row_ptr(buf, 0, c.halo_lo ? c.rr : c.rr - 1) + c.x0);
-        const float4 yp = c.halo_hi ? hc : lds_ld4(c.row_ptr(buf, 0, c.halo_hi ? c.rr : c.rr + 1) + c.x0);
-        const float e = jrow[c.xe];
-        const float left = from_lane_below(jc.w, e, c.lane);
-        const float right = from_lane_above(jc.x, e, c.lane);
+    if (do1) {
+        const float left = from_lane_below(jc.w, je, c.lane);
+        const float right = from_lane_above(jc.x, je, c.lane);
         float4 n;
-        n.x = canon_num(b_c.x, jc.y, yp.x, jn.x, left, ym.x, jm.x);
-        n.y = canon_num(b_c.y, jc.z, yp.y, jn.y, jc.x, ym.y, jm.y);
-        n.z = canon_num(b_c.z, jc.w, yp.z, jn.z, jc.y, ym.z, jm.z);
-        n.w = canon_num(b_c.w, right, yp.w, jn.w, jc.z, ym.w, jm.w);
-        const float4 o = canon_div4(n, m_c, c.divtab);
+        n.x = canon_num(b_c.x, jc.y, jyp.x, jn.x, left, jym.x, jm.x);
+        n.y = canon_num(b_c.y, jc.z, jyp.y, jn.y, jc.x, jym.y, jm.y);
+        n.z = canon_num(b_c.z, jc.w, jyp.z, jn.z, jc.y, jym.z, jm.z);
+        n.w = canon_num(b_c.w, right, jyp.w, jn.w, jc.z, jym.w, jm.w);
+        const float4 o = canon_div4(n, m_c, d_c);
         s_c.x = mask_is_water(m_c, 0) ? o.x : jc.x;
         s_c.y = mask_is_water(m_c, 1) ? o.y : jc.y;
         s_c.z = mask_is_water(m_c, 2) ? o.z : jc.z;
         s_c.w = mask_is_water(m_c, 3) ? o.w : jc.w;
     }
+#ifdef FLUID_FUSED_TRACE
+    asm volatile("" ::"v"(s_c.x), "v"(s_c.y), "v"(s_c.z), "v"(s_c.w));  // stage 1 is done here
+#endif
+    FT(3);  // LDS round trip + stage 1
 
     // ---- stage 2: iterate j+2 at plane zc-1 from iterate j+1 at planes zc-2, zc-1, zc
-    const int zo = zc - 1;
-    if (zo >= c.zb && zo < c.ze && c.rr >= 1 && c.rr <= R - 2) {  // wave-uniform
-        const bool wet = c.is_out_row && mask_any_water(m_m);
-        if (__builtin_amdgcn_ballot_w64(wet) != 0ull) {
-            const float4 ym = lds_ld4(c.row_ptr(buf, 1, c.rr - 1) + c.x0);
-            const float4 yp = lds_ld4(c.row_ptr(buf, 1, c.rr + 1) + c.x0);
-            const float e = srow[c.xe];
-            const float left = from_lane_below(s_m.w, e, c.lane);
-            const float right = from_lane_above(s_m.x, e, c.lane);
-            float4 n;
-            n.x = canon_num(b_m.x, s_m.y, yp.x, s_c.x, left, ym.x, s_mm.x);
-            n.y = canon_num(b_m.y, s_m.z, yp.y, s_c.y, s_m.x, ym.y, s_mm.y);
-            n.z = canon_num(b_m.z, s_m.w, yp.z, s_c.z, s_m.y, ym.z, s_mm.z);
-            n.w = canon_num(b_m.w, right, yp.w, s_c.w, s_m.z, ym.w, s_mm.w);
-            float4 o = canon_div4(n, m_m, c.divtab);
-            o.x = mask_is_water(m_m, 0) ? o.x : s_m.x;
-            o.y = mask_is_water(m_m, 1) ? o.y : s_m.y;
-            o.z = mask_is_water(m_m, 2) ? o.z : s_m.z;
-            o.w = mask_is_water(m_m, 3) ? o.w : s_m.w;
-            if (wet) {
-                const int64_t oo = (int64_t)zo * c.plane;
-                st_f4(c.pout + oo, c.boff, o);
-                if (c.pmid)  // the odd iterate, kept only by the last pair of a loop
-                    st_f4(c.pmid + oo, c.boff, s_m);
-            }
+    if (do2) {
+        const float left = from_lane_below(s_m.w, se, c.lane);
+        const float right = from_lane_above(s_m.x, se, c.lane);
+        float4 n;
+        n.x = canon_num(b_m.x, s_m.y, syp.x, s_c.x, left, sym.x, s_mm.x);
+        n.y = canon_num(b_m.y, s_m.z, syp.y, s_c.y, s_m.x, sym.y, s_mm.y);
+        n.z = canon_num(b_m.z, s_m.w, syp.z, s_c.z, s_m.y, sym.z, s_mm.z);
+        n.w = canon_num(b_m.w, right, syp.w, s_c.w, s_m.z, sym.w, s_mm.w);
+        float4 o = canon_div4(n, m_m, d_m);
+        o.x = mask_is_water(m_m, 0) ? o.x : s_m.x;
+        o.y = mask_is_water(m_m, 1) ? o.y : s_m.y;
+        o.z = mask_is_water(m_m, 2) ? o.z : s_m.z;
+        o.w = mask_is_water(m_m, 3) ? o.w : s_m.w;
+        if (wet) {
+            const int64_t oo = (int64_t)zo * c.plane;
+            st_f4(c.pout + oo, c.boff, o);
+            if (c.pmid)  // the odd iterate, kept only by the last pair of a loop
+                st_f4(c.pmid + oo, c.boff, s_m);
         }
     }
+    FT(4);  // stage 2 + stores
 }
 
 template <int NT, bool WIN>
@@ -403,7 +467,7 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         c.pad_x = c.lane == 0 ? -1 : NT * 256;
     }
 
-    {   // DivEntry table (before the first barrier of the march, which orders it with its readers)
+    {   // DivEntry table
         FLUID_LDS float* tab = c.lds + 2 * 2 * R * RW;  // DivEntry {a, r} pairs
         c.divtab = (const FLUID_LDS char*)tab;
         if (threadIdx.x < DIV_TABLE_ENTRIES) {
@@ -419,6 +483,8 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         base[side < FUSED_PAD ? side : RW - 2 * FUSED_PAD + side] = p_air;
     }
 
+    __syncthreads();  // the table is read before the first barrier of the march (div_pairs)
+
     // prologue: the state a step with ring phase 0 and zc = zb - 1 expects
     const float4 pa4 = make_float4(p_air, p_air, p_air, p_air);
     FusedState st;
@@ -433,6 +499,7 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     st.m[1] = MASK_DRY4;
     st.b[2] = ld_f4(rhs + c.m_off(zc), c.boff);
     st.m[2] = ld_u32(mask + c.m_off(zc), c.boff >> 2);
+    for (int i = 0; i < 4; i++) st.dv[0].c[i] = st.dv[1].c[i] = make_float2(0.f, 0.f);
     if (WIN) {
         auto pad_at = [&](int lz) {
             return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pin + c.j_off(lz)) +
@@ -443,15 +510,31 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     }
 
     const int steps = c.ze - c.zb + 2;  // iterate j+1 at planes zb-1 .. ze, iterate j+2 one behind
+#ifdef FLUID_FUSED_TRACE
+    FusedTrace ftr;
+    for (int i = 0; i < FUSED_TRACE_PHASES; i++) ftr.sum[i] = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step<NT, 0, WIN>(c, st, zc);
+        fused_step<NT, 0, WIN>(c, st, zc FLUID_TRACE_PASS);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step<NT, 1, WIN>(c, st, zc + 1);
+        fused_step<NT, 1, WIN>(c, st, zc + 1 FLUID_TRACE_PASS);
         if (k + 2 >= steps) break;
-        fused_step<NT, 2, WIN>(c, st, zc + 2);
+        fused_step<NT, 2, WIN>(c, st, zc + 2 FLUID_TRACE_PASS);
         if (k + 3 >= steps) break;
-        fused_step<NT, 3, WIN>(c, st, zc + 3);
+        fused_step<NT, 3, WIN>(c, st, zc + 3 FLUID_TRACE_PASS);
     }
+#ifdef FLUID_FUSED_TRACE
+    {
+        const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (wg < 64 && c.lane == 0) {
+            unsigned long long* o = g_fused_trace + (wg * 16 + wave) * (FUSED_TRACE_PHASES + 1);
+            ftr.sum[5] = __builtin_amdgcn_s_memtime() - t_begin;  // whole march
+            for (int i = 0; i < FUSED_TRACE_PHASES; i++) o[i] = ftr.sum[i];
+            o[FUSED_TRACE_PHASES] = (unsigned long long)steps;
+        }
+    }
+#endif
 }
 
 }  // namespace fluid

@@ -45,3 +45,10 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
 }
 
 }  // namespace fluid
+
+#ifdef FLUID_FUSED_TRACE
+// dev build: copy the phase sums of the last launch out (tools/fused_trace.py)
+extern "C" int fluid_dev_fused_trace(unsigned long long* out, int words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fluid::g_fused_trace), sizeof(unsigned long long) * words);
+}
+#endif

@@ -238,22 +238,37 @@ struct RcclApi {
                               hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-// librccl on demand: the library this process already has (a host program that links it, or torch's) if
-// any, else the ROCm installation's.  Returns null and a message when there is none.
+// librccl on demand.  It must sit on the SAME HIP runtime as this library: streams and device pointers
+// are handles of one runtime instance, and a process may hold two (PyTorch wheels bundle their own
+// libamdhip64 / libhsa-runtime64 / librccl next to the ROCm installation's).  So: find the file the HIP
+// runtime this library is bound to was loaded from, and take the librccl of that directory — deep-bound, so
+// that its own HIP calls resolve to that runtime too, whatever else is in the global scope.
 const RcclApi* rccl_api(std::string& why) {
     static RcclApi api;
     static bool tried = false;
     static std::string failure;
     if (!tried) {
         tried = true;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names)
-            if ((api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-        if (!api.lib)
-            for (const char* n : names)
-                if ((api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        std::vector<std::string> names;
+        Dl_info where{};
+        if (dladdr(reinterpret_cast<void*>(&hipStreamCreateWithFlags), &where) && where.dli_fname) {
+            std::string dir = where.dli_fname;
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
+        std::string tried_names;
+        for (const std::string& n : names) {
+            if ((api.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND))) break;
+            tried_names += " " + n;
+        }
         if (!api.lib) {
-            failure = std::string("librccl could not be loaded: ") + dlerror();
+            failure = std::string("librccl could not be loaded (tried") + tried_names + "): " + dlerror();
         } else {
             auto sym = [&](const char* n) {
                 void* p = dlsym(api.lib, n);

@@ -158,26 +158,24 @@ def partition_z(depth: int, world: int) -> List[Tuple[int, int]]:
 class DistContext:
     rank: int
     world: int
-    device: object  # torch.device
+    device: int   # HIP device ordinal of this process (LOCAL_RANK)
     backend: str
 
 
 def init_distributed(local_rank: int = 0, backend: Optional[str] = None) -> DistContext:
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  The group is
-    used for bootstrap and measurement only (unique id broadcast, barriers, MAX of the timings): gloo is
-    enough, and is the default when no backend is asked for."""
-    import torch
+    used for bootstrap and measurement only (unique id broadcast, barriers, MAX of the timings) and runs
+    over gloo on host tensors: torch never touches the GPU here.  The engine library is loaded first, so
+    that it binds the ROCm installation's HIP runtime rather than the one a PyTorch wheel bundles (the
+    driver then takes the librccl that belongs to that runtime, csrc/slab_driver.hip: rccl_api)."""
+    E.load_library()
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    use_gpu = torch.cuda.is_available()
-    if use_gpu:
-        torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
     if not dist.is_initialized():
         dist.init_process_group(backend=backend or "gloo")
-    return DistContext(dist.get_rank(), dist.get_world_size(), device, dist.get_backend())
+    return DistContext(dist.get_rank(), dist.get_world_size(), local_rank, dist.get_backend())
 
 
 # ---- callback transport over torch.distributed --------------------------------------------------------
@@ -196,7 +194,7 @@ class TorchDistTransport:
         self.error = None
         self._hip = None
         if device_memory:
-            self._hip = C.CDLL("libamdhip64.so")
+            self._hip = C.CDLL("libamdhip64.so.7")  # by soname: the runtime the engine library is bound to
             self._hip.hipMemcpy.restype = C.c_int
             self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.table = TransportTable()
@@ -437,10 +435,7 @@ class SlabDriver:
     # -- transport ------------------------------------------------------------------------------------
     def attach_rccl(self):
         """RCCL point-to-point between the GPUs: rank 0 makes the unique id, the torch.distributed group
-        (any backend) carries it to the others, every rank initialises its communicator."""
-        import torch
-        import torch.distributed as dist
-
+        (gloo; host tensors) carries it to the others, every rank initialises its communicator."""
         buf = (C.c_uint8 * RCCL_ID_BYTES)()
         if self.rank == 0:
             rc = self._lib.fluid_slab_rccl_unique_id(buf)
@@ -448,11 +443,12 @@ class SlabDriver:
                 msg = self._lib.fluid_slab_last_error(None)
                 raise SlabError(rc, msg.decode() if msg else "")
         if self.world > 1:
+            import torch
+            import torch.distributed as dist
+
             t = torch.tensor(list(buf), dtype=torch.uint8)
-            if dist.get_backend() == "nccl":
-                t = t.cuda()
             dist.broadcast(t, src=0)
-            buf = (C.c_uint8 * RCCL_ID_BYTES)(*t.cpu().tolist())
+            buf = (C.c_uint8 * RCCL_ID_BYTES)(*t.tolist())
         self._check(self._lib.fluid_slab_attach_rccl(self._h, buf))
 
     def attach_torch_transport(self, device_memory: bool = False):
@@ -553,7 +549,7 @@ class SlabDriver:
 
         w, h, d = size
         drv = cls(default_params(w, h, d, 0), ctx.rank, ctx.world, pressure_iterations=iterations,
-                  device=ctx.device.index if ctx.device.index is not None else -1, **kw)
+                  device=ctx.device, **kw)
         if ctx.world > 1:
             drv.attach_rccl()
         z0, n = drv.slab
@@ -595,10 +591,8 @@ class SlabDriver:
             self.engine.enable_timing(False)
         vals = torch.tensor([wall, ms / max(calls, 1)], dtype=torch.float64)
         if multi:
-            if dist.get_backend() == "nccl":
-                vals = vals.cuda()
             dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-        wall, kernel = (float(v) for v in vals.cpu())
+        wall, kernel = (float(v) for v in vals)
         w, h, _ = self.params.size
         return {"wall_s": wall, "local_cells": w * h * self.slab[1], "halo_overlap": probe,
                 "kernel_ms_per_sweep": kernel,
@@ -630,10 +624,8 @@ class SlabDriver:
             step()
             self._store().sync()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            if dist.get_backend() == "nccl":
-                t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            times[mode] = float(t.cpu()[0])
+            times[mode] = float(t[0])
         best = min(times, key=times.get)
         self.set_option(OPT_OVERLAP, best)
         return {"used": best, "probed": True, "step_ms_inline": 1e3 * times[OVERLAP_NONE],
