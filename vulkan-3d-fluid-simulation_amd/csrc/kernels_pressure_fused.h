@@ -146,16 +146,28 @@ struct FusedTrace {
 #define FT(i)
 #endif
 
-constexpr int FUSED_WAVES = 16;
-constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int FUSED_PAD = 4;  // floats of padding on each side of an LDS row (keeps rows 16-B aligned)
 
-__host__ __device__ inline int fused_row_floats(int nt) { return nt * 256 + 2 * FUSED_PAD; }
-__host__ __device__ inline size_t fused_lds_bytes(int nt) {
-    const int r = FUSED_WAVES / nt;
-    return (size_t)2 /*buffers*/ * 2 /*J,S*/ * r * fused_row_floats(nt) * sizeof(float) +
-           128 /* DivEntry table */;
-}
+// Shape of a workgroup.  NT = 256-cell x tiles per row (the workgroup spans the whole x extent, or the
+// window), RG = rows per wavefront.  RG = 1: 16 wavefronts of one row each.  RG >= 2: 8 wavefronts (two
+// per SIMD, 256 VGPRs each) that own RG adjacent rows each: the y neighbours inside a wavefront's rows
+// are registers, only the group's edge rows go through LDS, the per-wavefront overhead of a plane step
+// (addresses, waits, the barrier) is paid once per RG rows, and RG independent rows interleave in the
+// one instruction stream — the SIMDs execute their wavefronts one after the other (oldest first) between
+// two barriers, so work per wavefront, not wavefronts per SIMD, is what fills the VALU.
+constexpr int fused_waves(int rg) { return rg == 1 ? 16 : 8; }
+template <int NT, int RG>
+struct FusedGeom {
+    static constexpr int WAVES = fused_waves(RG);
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int GROUPS = WAVES / NT;  // row groups = wavefronts per x tile
+    static constexpr int R = GROUPS * RG;      // rows of iterate j+1 per workgroup
+    static constexpr int TY = R - 2;           // output rows per workgroup
+    static constexpr int RW = NT * 256 + 2 * FUSED_PAD;
+    static_assert(GROUPS >= 2, "a wavefront is the lower or the upper edge of its workgroup, not both");
+    static constexpr size_t lds_bytes =
+        (size_t)2 /*buffers*/ * 2 /*J,S*/ * R * RW * sizeof(float) + 128 /* DivEntry table */;
+};
 
 // Plane ranges of one launch (local plane indices; ghost planes are negative or >= Dl):
 //   [zout_lo, zout_hi)  planes of iterate j+2 this launch writes.  On a Z slab it may reach into the
@@ -170,40 +182,38 @@ __host__ __device__ inline size_t fused_lds_bytes(int nt) {
 //                       planes near its faces and the planes in between in separate launches, so that
 //                       the halo exchange overlaps the larger one); nz_lo = z-chunks below the hole.
 //                       No hole: hole_lo = hole_hi = zout_hi, nz_lo = all chunks.
-//   xwin0               (k12_canon2<NT, true> only) global x of the workgroups' first cell: the launch
+//   xwin0               (WIN kernels only) global x of the workgroups' first cell: the launch
 //                       covers the window [xwin0, xwin0 + NT*256) of every row instead of the whole row.
 //                       Valid when every water cell of the grid lies inside the window: the columns
 //                       just outside it then hold non-water constants, the same in every iterate, which
 //                       the edge lanes load into the pad cells of the LDS rows.
-//   xcd_rows, xcd_nz    (experiment) > 0: the launch is a 1-D grid; workgroup L runs on XCD L % 8 (the
-//                       dispatcher deals workgroups to the 8 XCDs in turn) and takes tile L / 8 of that
-//                       XCD's own list — a band of row tiles x all z chunks — so that workgroups which
-//                       share halo rows share an L2.  xcd_rows = row tiles in the launch, xcd_nz = chunks.
+//   xcd_rows, xcd_nz    > 0: the launch is a 1-D grid; workgroup L runs on XCD L % 8 (the dispatcher deals
+//                       workgroups to the 8 XCDs in turn) and takes tile L / 8 of that XCD's own list — a
+//                       band of row tiles x all z chunks — so that workgroups which share halo rows share
+//                       an L2.  xcd_rows = row tiles in the launch, xcd_nz = chunks.
 struct FusedRange {
     int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0, xcd_rows, xcd_nz;
 };
 
-// Per-wavefront state of the z march.  Everything rotates with period 4 (the z loop is unrolled by
-// 4, so ring indices are compile-time constants and the rotation costs no register moves):
+// State of one row of a wavefront during the z march.  Everything rotates with period 4 (the z loop is
+// unrolled by 4, so ring indices are compile-time constants and the rotation costs no register moves):
 //   j[4]  iterate j   : slots (i, i+1, i+2) = planes zc-1, zc, zc+1; slot i+3 receives plane zc+2
 //   s[4]  iterate j+1 : slots (i, i+1) = planes zc-2, zc-1; slot i+2 receives plane zc
 //   b[4], m[4]        : slots (i+1, i+2) = planes zc-1 (stage 2), zc (stage 1); slot i+3 receives zc+1
-//   h[2]  halo row    : slot i&1 = plane zc; the other receives plane zc+1   (halo wavefronts only)
 //   padv[4] (windowed launches) : iterate j at the column just outside the window, slots (i, i+1) =
 //                                  planes zc-1, zc; slot i+2 receives plane zc+1
-//   dv[2] (a, 1/a) pairs : slot i&1 = of the mask word of plane zc (stage 1 of this step), fetched before this
-//                          step's barrier; the other slot = of plane zc-1, fetched a step ago (stage 2)
-struct FusedState {
-    float4 j[4], s[4], b[4], h[2];
+struct FusedRow {
+    float4 j[4], s[4], b[4];
     uint32_t m[4];
     float padv[4];
-    DivPairs dv[2];
+    unsigned boff, boff_pad;  // in-plane byte offsets of this lane's cells / of its pad column in this row
+    bool row_in, pad_in;      // those cells exist
+    bool is_out_row;          // ... and the row is one the workgroup writes
 };
 
-template <int NT>
+template <int NT, int RG>
 struct FusedCtx {
-    static constexpr int R = FUSED_WAVES / NT;
-    static constexpr int RW = NT * 256 + 2 * FUSED_PAD;
+    using G = FusedGeom<NT, RG>;
     const uint8_t* mask;
     const float* rhs;
     const float* pin;
@@ -216,26 +226,24 @@ struct FusedCtx {
     int jlo, jhi;  // local planes [jlo, jhi) of the working buffers hold cells of the grid: the owned
                    // planes plus two ghost planes per side where a neighbouring slab exists
     int mlo, mhi;  // same for mask / b_i (one ghost plane per side)
-    int lane, rr, x0, xe;
-    unsigned boff, boff_h;
-    // windowed launches: byte offset of this lane's pad column (left for lanes < 32, right otherwise) in
-    // its row, whether that cell exists, whether this lane stores a pad cell and where (LDS x index)
-    unsigned boff_pad;
-    bool pad_in, pad_writer;
+    int lane, rr0, x0, xe;  // rr0 = first row (within the workgroup) of this wavefront's group
+    unsigned boff_h;        // the row just outside the workgroup (edge wavefronts)
+    bool pad_writer;
     int pad_x;
     float p_oob;
-    bool row_in, halo_in, halo_lo, halo_hi, is_out_row;
-    bool wave_clean;     // every lane of this wavefront lies inside the grid (wave-uniform)
-    uint32_t lane_mask;  // ~0 for lanes inside the grid
+    bool halo_in;           // per lane: that outer row's cells exist
+    bool halo_lo, halo_hi;  // wave-uniform: this group holds row 0 / row R-1 of the workgroup, which only
+                            // form iterate j+1 and whose outer y neighbour comes from global memory
+    bool wave_clean;        // every cell of this wavefront (and of its outer row) lies inside the grid
 
     __device__ __forceinline__ FLUID_LDS float* row_ptr(int buf, int arr, int row) const {
-        return lds + ((buf * 2 + arr) * R + row) * RW + FUSED_PAD;
+        return lds + ((buf * 2 + arr) * G::R + row) * G::RW + FUSED_PAD;
     }
     __device__ __forceinline__ bool j_ok(int lz) const { return lz >= jlo && lz < jhi; }
     __device__ __forceinline__ bool m_ok(int lz) const { return lz >= mlo && lz < mhi; }
     // element offset of plane lz, redirected to plane 0 when lz is outside the grid: loads are always
-    // issued, from a valid address, and the value is replaced later (fix_*).  A branch or a select
-    // directly on a load makes hipcc wait for it (vmcnt(0)) on the spot.
+    // issued, from a valid address, and the value is replaced later (fix_*).  A select directly on a
+    // load makes hipcc wait for it (vmcnt(0)) on the spot.
     __device__ __forceinline__ int64_t j_off(int lz) const {
         return j_ok(lz) ? (int64_t)lz * plane : (int64_t)0;
     }
@@ -247,144 +255,208 @@ struct FusedCtx {
         const float4 pa4 = make_float4(p_oob, p_oob, p_oob, p_oob);
         return (ok && j_ok(lz)) ? v : pa4;
     }
-    __device__ __forceinline__ float fix_pad(float v, int lz) const {
+    __device__ __forceinline__ float fix_pad(float v, bool pad_in, int lz) const {
         return (pad_in && j_ok(lz)) ? v : p_oob;
     }
-    __device__ __forceinline__ uint32_t fix_m(uint32_t m, int lz) const {
+    __device__ __forceinline__ uint32_t fix_m(uint32_t m, bool row_in, int lz) const {
         if (wave_clean && m_ok(lz)) return m;
-        return m_ok(lz) ? ((m & lane_mask) | (MASK_DRY4 & ~lane_mask)) : MASK_DRY4;
+        return (m_ok(lz) && row_in) ? m : MASK_DRY4;
     }
 };
 
-// One plane step: I = ring phase (k mod 4), zc = plane of iterate j+1 formed in this step.
-template <int NT, int I, bool WIN>
-__device__ __forceinline__ void fused_step(const FusedCtx<NT>& c, FusedState& st, int zc FLUID_TRACE_ARG) {
-    constexpr int R = FusedCtx<NT>::R;
-    constexpr int buf = I & 1;
-    float4& jm = st.j[I & 3];
-    float4& jc = st.j[(I + 1) & 3];
-    float4& jn = st.j[(I + 2) & 3];   // raw from the previous step's load until fixed up below
-    float4& s_mm = st.s[I & 3];
-    float4& s_m = st.s[(I + 1) & 3];
-    float4& s_c = st.s[(I + 2) & 3];
-    const float4 b_m = st.b[(I + 1) & 3], b_c = st.b[(I + 2) & 3];
-    const uint32_t m_m = st.m[(I + 1) & 3];
-
-    FT_BEGIN();
-    // ---- loads the next step needs (raw; fixed up at the end of this step)
-    const int64_t o1 = c.j_off(zc + 1), o2 = c.j_off(zc + 2), a1 = c.m_off(zc + 1);
-    st.j[(I + 3) & 3] = ld_f4(c.pin + o2, c.boff);
-    st.h[(I + 1) & 1] = ld_f4(c.pin + o1, c.boff_h);
-    st.b[(I + 3) & 3] = ld_f4(c.rhs + a1, c.boff);
-    st.m[(I + 3) & 3] = ld_u32(c.mask + a1, c.boff >> 2);
-    if (WIN)
-        st.padv[(I + 2) & 3] =
-            *reinterpret_cast<const float*>(reinterpret_cast<const char*>(c.pin + o1) + c.boff_pad);
-
-    // ---- what the previous step loaded, fixed up (only wavefronts / planes on the grid boundary do
-    // anything here; those loads have had a whole step to land): known BEFORE the barrier, so the
-    // decisions and the table look-ups that depend on the mask word are taken off the path behind it
-    jn = c.fix_j(jn, c.row_in, zc + 1);
-    const float4 hc = c.fix_j(st.h[I & 1], c.halo_in, zc);
-    const uint32_t m_c = c.fix_m(st.m[(I + 2) & 3], zc);
-    st.m[(I + 2) & 3] = m_c;
-    const int zo = zc - 1;
-    const bool do1 = __builtin_amdgcn_ballot_w64(mask_any_water(m_c)) != 0ull;            // wave-uniform
-    const bool wet = c.is_out_row && mask_any_water(m_m);
-    const bool do2 = zo >= c.zb && zo < c.ze && c.rr >= 1 && c.rr <= R - 2 &&            // wave-uniform
-                     __builtin_amdgcn_ballot_w64(wet) != 0ull;
-    FT(0);  // issue of the loads + wait for the previous step's
-    if (do1) st.dv[I & 1] = div_pairs(m_c, c.divtab);  // stage 2 of the next step uses them again
-    const DivPairs& d_c = st.dv[I & 1];
-    const DivPairs& d_m = st.dv[(I + 1) & 1];
-
-    // ---- publish this row: iterate j at plane zc, iterate j+1 at plane zc-1
-    FLUID_LDS float* jrow = c.row_ptr(buf, 0, c.rr);
-    FLUID_LDS float* srow = c.row_ptr(buf, 1, c.rr);
-    lds_st4(jrow + c.x0, jc);
-    lds_st4(srow + c.x0, s_m);
-    if (WIN) {
-        // the columns next to the window hold non-water constants: the same value in both iterates
-        if (c.pad_writer) {
-            jrow[c.pad_x] = c.fix_pad(st.padv[(I + 1) & 3], zc);
-            srow[c.pad_x] = c.fix_pad(st.padv[I & 3], zc - 1);
-        }
-    }
-    FT(1);  // publish
-    __syncthreads();
-    FT(2);  // barrier
-
-    // ---- the neighbour rows of both stages in ONE round trip to LDS
-    float4 jym = hc, jyp = hc, sym = s_m, syp = s_m;
-    float je = 0.f, se = 0.f;
-    if (do1) {
-        if (!c.halo_lo) jym = lds_ld4(c.row_ptr(buf, 0, c.rr - 1) + c.x0);
-        if (!c.halo_hi) jyp = lds_ld4(c.row_ptr(buf, 0, c.rr + 1) + c.x0);
-        je = jrow[c.xe];
-    }
-    if (do2) {
-        sym = lds_ld4(c.row_ptr(buf, 1, c.rr - 1) + c.x0);
-        syp = lds_ld4(c.row_ptr(buf, 1, c.rr + 1) + c.x0);
-        se = srow[c.xe];
-    }
-
-    // ---- stage 1: iterate j+1 at plane zc for this row
-    s_c = jc;  // non-water (and out-of-grid) cells keep their constant
-    if (do1) {
-        const float left = from_lane_below(jc.w, je, c.lane);
-        const float right = from_lane_above(jc.x, je, c.lane);
-        float4 n;
-        n.x = canon_num(b_c.x, jc.y, jyp.x, jn.x, left, jym.x, jm.x);
-        n.y = canon_num(b_c.y, jc.z, jyp.y, jn.y, jc.x, jym.y, jm.y);
-        n.z = canon_num(b_c.z, jc.w, jyp.z, jn.z, jc.y, jym.z, jm.z);
-        n.w = canon_num(b_c.w, right, jyp.w, jn.w, jc.z, jym.w, jm.w);
-        const float4 o = canon_div4(n, m_c, d_c);
-        s_c.x = mask_is_water(m_c, 0) ? o.x : jc.x;
-        s_c.y = mask_is_water(m_c, 1) ? o.y : jc.y;
-        s_c.z = mask_is_water(m_c, 2) ? o.z : jc.z;
-        s_c.w = mask_is_water(m_c, 3) ? o.w : jc.w;
-    }
-#ifdef FLUID_FUSED_TRACE
-    asm volatile("" ::"v"(s_c.x), "v"(s_c.y), "v"(s_c.z), "v"(s_c.w));  // stage 1 is done here
-#endif
-    FT(3);  // LDS round trip + stage 1
-
-    // ---- stage 2: iterate j+2 at plane zc-1 from iterate j+1 at planes zc-2, zc-1, zc
-    if (do2) {
-        const float left = from_lane_below(s_m.w, se, c.lane);
-        const float right = from_lane_above(s_m.x, se, c.lane);
-        float4 n;
-        n.x = canon_num(b_m.x, s_m.y, syp.x, s_c.x, left, sym.x, s_mm.x);
-        n.y = canon_num(b_m.y, s_m.z, syp.y, s_c.y, s_m.x, sym.y, s_mm.y);
-        n.z = canon_num(b_m.z, s_m.w, syp.z, s_c.z, s_m.y, sym.z, s_mm.z);
-        n.w = canon_num(b_m.w, right, syp.w, s_c.w, s_m.z, sym.w, s_mm.w);
-        float4 o = canon_div4(n, m_m, d_m);
-        o.x = mask_is_water(m_m, 0) ? o.x : s_m.x;
-        o.y = mask_is_water(m_m, 1) ? o.y : s_m.y;
-        o.z = mask_is_water(m_m, 2) ? o.z : s_m.z;
-        o.w = mask_is_water(m_m, 3) ? o.w : s_m.w;
-        if (wet) {
-            const int64_t oo = (int64_t)zo * c.plane;
-            st_f4(c.pout + oo, c.boff, o);
-            if (c.pmid)  // the odd iterate, kept only by the last pair of a loop
-                st_f4(c.pmid + oo, c.boff, s_m);
-        }
-    }
-    FT(4);  // stage 2 + stores
+// the four cells of a lane: numerators from the six neighbours, quotients, water cells take them
+__device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, float4 yp, float4 zp,
+                                             float4 ym, float4 zm, float left, float right,
+                                             const DivPairs& d) {
+    float4 n;
+    n.x = canon_num(b.x, c.y, yp.x, zp.x, left, ym.x, zm.x);
+    n.y = canon_num(b.y, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
+    n.z = canon_num(b.z, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
+    n.w = canon_num(b.w, right, yp.w, zp.w, c.z, ym.w, zm.w);
+    float4 o = canon_div4(n, m, d);
+    o.x = mask_is_water(m, 0) ? o.x : c.x;  // non-water (and out-of-grid) cells keep their constant
+    o.y = mask_is_water(m, 1) ? o.y : c.y;
+    o.z = mask_is_water(m, 2) ? o.z : c.z;
+    o.w = mask_is_water(m, 3) ? o.w : c.w;
+    return o;
 }
 
-template <int NT, bool WIN>
-__global__ void __launch_bounds__(FUSED_THREADS)
+// One plane step: I = ring phase (k mod 4), zc = plane of iterate j+1 formed in this step.  A step begins
+// right behind the barrier that made the rows of plane zc (iterate j) and zc-1 (iterate j+1) visible, and
+// ends with the barrier of the next one.  All wavefronts of a workgroup move through it in lock step, so a
+// resource used in one burst (the 16 wavefronts' loads in the texture addresser, their LDS reads) idles
+// the others; the order below spreads them out:
+//   LDS reads -> loads of iterate j two planes ahead -> (wait for the loads of the PREVIOUS step) fix-ups,
+//   table look-ups -> stage 1 -> loads of b_i / mask one plane ahead -> stage 2 -> stores -> publish -> barrier.
+// Vector-memory operations retire in issue order and the compiler's s_waitcnt counts only what is issued
+// on every path, so the stores carry all their conditions in the EXEC mask (no branch around them): the
+// wait for a step's loads then never includes the stores issued after them.
+template <int NT, int RG, int I, bool WIN, bool KEEP>
+__device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (&row)[RG], float4 (&h)[2],
+                                           int zc FLUID_TRACE_ARG) {
+    constexpr int buf = I & 1;
+    constexpr int JM = I & 3, JC = (I + 1) & 3, JN = (I + 2) & 3, JL = (I + 3) & 3;  // j ring
+    constexpr int SMM = I & 3, SM = (I + 1) & 3, SC = (I + 2) & 3;                    // s ring
+    constexpr int BM = (I + 1) & 3, BC = (I + 2) & 3, BL = (I + 3) & 3;               // b, m rings
+    constexpr bool X_EDGE_FROM_LDS = NT > 1 || WIN;  // else the cells beyond the row ends are p_oob
+    const bool is_halo = c.halo_lo || c.halo_hi;     // wave-uniform
+
+    FT_BEGIN();
+    // ---- everything both stages need from LDS, in one round trip: the rows next to the group, the cells
+    // across the x-tile seams
+    float4 jext_lo, jext_hi, sext_lo, sext_hi;
+    float je[RG], se[RG];
+    if (!c.halo_lo) {
+        jext_lo = lds_ld4(c.row_ptr(buf, 0, c.rr0 - 1) + c.x0);
+        sext_lo = lds_ld4(c.row_ptr(buf, 1, c.rr0 - 1) + c.x0);
+    }
+    if (!c.halo_hi) {
+        jext_hi = lds_ld4(c.row_ptr(buf, 0, c.rr0 + RG) + c.x0);
+        sext_hi = lds_ld4(c.row_ptr(buf, 1, c.rr0 + RG) + c.x0);
+    }
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        je[i] = X_EDGE_FROM_LDS ? c.row_ptr(buf, 0, c.rr0 + i)[c.xe] : c.p_oob;
+        se[i] = X_EDGE_FROM_LDS ? c.row_ptr(buf, 1, c.rr0 + i)[c.xe] : c.p_oob;
+    }
+
+    // ---- iterate j two planes ahead (raw; fixed up in the next step)
+    const int64_t o2 = c.j_off(zc + 2);
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        row[i].j[JL] = ld_f4(c.pin + o2, row[i].boff);
+        if (WIN)
+            row[i].padv[(I + 3) & 3] = *reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(c.pin + o2) + row[i].boff_pad);
+    }
+
+    // ---- what the previous step loaded, fixed up (only wavefronts / planes on the grid boundary do
+    // anything here; those loads have had a whole step to land)
+    uint32_t m_c[RG];
+    bool water1 = false, wet2 = false;
+    bool wet[RG];
+    const int zo = zc - 1;
+    const bool zo_in = zo >= c.zb && zo < c.ze;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        row[i].j[JN] = c.fix_j(row[i].j[JN], row[i].row_in, zc + 1);
+        m_c[i] = c.fix_m(row[i].m[BC], row[i].row_in, zc);
+        row[i].m[BC] = m_c[i];
+        water1 = water1 || mask_any_water(m_c[i]);
+        wet[i] = zo_in && row[i].is_out_row && mask_any_water(row[i].m[BM]);
+        wet2 = wet2 || wet[i];
+    }
+    if (is_halo) {
+        const float4 hc = c.fix_j(h[I & 1], c.halo_in, zc);
+        if (c.halo_lo) jext_lo = hc; else jext_hi = hc;
+        if (c.halo_lo) sext_lo = hc; else sext_hi = hc;  // not used: the edge row forms no iterate j+2
+    }
+    const bool do1 = __builtin_amdgcn_ballot_w64(water1) != 0ull;  // wave-uniform
+    const bool do2 = __builtin_amdgcn_ballot_w64(wet2) != 0ull;    // wave-uniform
+    FT(0);  // LDS reads issued, j loads issued, wait for the previous step's loads
+
+    // ---- stage 1: iterate j+1 at plane zc for every row
+#pragma unroll
+    for (int i = 0; i < RG; i++) row[i].s[SC] = row[i].j[JC];  // non-water cells keep their constant
+    if (do1) {
+        DivPairs d1[RG];
+#pragma unroll
+        for (int i = 0; i < RG; i++) d1[i] = div_pairs(m_c[i], c.divtab);
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            const float4 jc = row[i].j[JC];
+            const float4 ym = i > 0 ? row[i > 0 ? i - 1 : 0].j[JC] : jext_lo;
+            const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].j[JC] : jext_hi;
+            const float left = from_lane_below(jc.w, je[i], c.lane);
+            const float right = from_lane_above(jc.x, je[i], c.lane);
+            row[i].s[SC] = canon_lane(row[i].b[BC], m_c[i], jc, yp, row[i].j[JN], ym, row[i].j[JM], left,
+                                      right, d1[i]);
+        }
+    }
+#ifdef FLUID_FUSED_TRACE
+    asm volatile("" ::"v"(row[0].s[SC].x), "v"(row[RG - 1].s[SC].w));  // stage 1 is done here
+#endif
+    FT(1);  // stage 1
+
+    // ---- b_i, mask (and the row outside the workgroup) one plane ahead
+    const int64_t o1 = c.j_off(zc + 1), a1 = c.m_off(zc + 1);
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        row[i].b[BL] = ld_f4(c.rhs + a1, row[i].boff);
+        row[i].m[BL] = ld_u32(c.mask + a1, row[i].boff >> 2);
+    }
+    if (is_halo) h[(I + 1) & 1] = ld_f4(c.pin + o1, c.boff_h);
+
+    // ---- stage 2: iterate j+2 at plane zc-1 from iterate j+1 at planes zc-2, zc-1, zc
+    float4 o[RG];
+#pragma unroll
+    for (int i = 0; i < RG; i++) o[i] = row[i].s[SM];
+    if (do2) {
+        DivPairs d2[RG];
+#pragma unroll
+        for (int i = 0; i < RG; i++) d2[i] = div_pairs(row[i].m[BM], c.divtab);
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            // rows 0 and R-1 of the workgroup only form iterate j+1 (wave-uniform tests)
+            if ((i == 0 && c.halo_lo) || (i == RG - 1 && c.halo_hi)) continue;
+            const float4 sm = row[i].s[SM];
+            const float4 ym = i > 0 ? row[i > 0 ? i - 1 : 0].s[SM] : sext_lo;
+            const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].s[SM] : sext_hi;
+            const float left = from_lane_below(sm.w, se[i], c.lane);
+            const float right = from_lane_above(sm.x, se[i], c.lane);
+            o[i] = canon_lane(row[i].b[BM], row[i].m[BM], sm, yp, row[i].s[SC], ym, row[i].s[SMM], left,
+                              right, d2[i]);
+        }
+    }
+    // stores: every condition is in the lane predicate (see above); a lane stores only if one of its
+    // four cells is water — the others hold the same constant in every working buffer
+    {
+        const int64_t oo = (int64_t)(zo_in ? zo : c.zb) * c.plane;
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            if (wet[i]) st_f4(c.pout + oo, row[i].boff, o[i]);
+            if (KEEP) {  // the odd iterate, kept only by the last pair of a loop
+                if (wet[i]) st_f4(c.pmid + oo, row[i].boff, row[i].s[SM]);
+            }
+        }
+    }
+    FT(2);  // b / mask loads, stage 2, stores
+
+    // ---- publish the rows for the next step: iterate j at plane zc+1, iterate j+1 at plane zc
+    constexpr int nbuf = buf ^ 1;
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        // rows inside a group are only needed across the x-tile seam
+        if (i == 0 || i == RG - 1 || X_EDGE_FROM_LDS) {
+            FLUID_LDS float* jrow = c.row_ptr(nbuf, 0, c.rr0 + i);
+            FLUID_LDS float* srow = c.row_ptr(nbuf, 1, c.rr0 + i);
+            lds_st4(jrow + c.x0, row[i].j[JN]);
+            lds_st4(srow + c.x0, row[i].s[SC]);
+            if (WIN) {
+                // the columns next to the window hold non-water constants: the same value in both iterates
+                if (c.pad_writer) {
+                    jrow[c.pad_x] = c.fix_pad(row[i].padv[(I + 2) & 3], row[i].pad_in, zc + 1);
+                    srow[c.pad_x] = c.fix_pad(row[i].padv[(I + 1) & 3], row[i].pad_in, zc);
+                }
+            }
+        }
+    }
+    FT(3);  // publish
+    __syncthreads();
+    FT(4);  // barrier
+}
+
+template <int NT, bool WIN, int RG, bool KEEP>
+__global__ void __launch_bounds__(fused_waves(RG) * 64)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
            const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pmid,
            const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk,
            FusedRange rg) {
-    constexpr int R = FUSED_WAVES / NT;   // rows of iterate j+1 per workgroup
-    constexpr int TY = R - 2;             // output rows per workgroup
-    constexpr int RW = NT * 256 + 2 * FUSED_PAD;
+    using G = FusedGeom<NT, RG>;
+    constexpr int R = G::R, TY = G::TY, RW = G::RW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    FusedCtx<NT> c;
+    FusedCtx<NT, RG> c;
     c.mask = mask;
     c.rhs = rhs;
     c.pin = pin;
@@ -399,11 +471,11 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.mhi = rg.mhi;
     c.p_oob = p_air;
     c.lane = threadIdx.x & 63;
-    // readfirstlane: tells hipcc the wave index (hence row, tile and halo role) is wave-uniform, so it
+    // readfirstlane: tells hipcc the wave index (hence rows, tile and edge role) is wave-uniform, so it
     // lives in SGPRs and role tests become scalar branches instead of exec masking
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = wave % NT;
-    c.rr = wave / NT;
+    c.rr0 = (wave / NT) * RG;
     c.x0 = tx * 256 + c.lane * 4;
     int tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
     if (rg.xcd_rows > 0) {
@@ -418,7 +490,6 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         tile_y = r0 + slot - tile_z * nr;
     }
     const int y0 = (tile_y + rg.ytile0) * TY;  // first output row
-    const int y = y0 - 1 + c.rr;           // this wavefront's row
     if (tile_z < rg.nz_lo) {
         c.zb = rg.zout_lo + tile_z * zchunk;
         c.ze = min(c.zb + zchunk, rg.hole_lo);
@@ -441,31 +512,35 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
 
     const int gx0 = (WIN ? rg.xwin0 : 0) + c.x0;     // global x of this lane's first cell
     const bool xin = gx0 < g.W;
-    c.row_in = xin && (unsigned)y < (unsigned)g.H;   // this lane's cells exist
-    c.is_out_row = c.rr >= 1 && c.rr <= R - 2 && c.row_in;
-    c.halo_lo = c.rr == 0;
-    c.halo_hi = c.rr == R - 1;
-    const int yh = c.halo_lo ? y - 1 : y + 1;        // outer neighbour row of a halo wavefront
+    const unsigned xs = xin ? (unsigned)gx0 : 0u;
+    c.halo_lo = c.rr0 == 0;
+    c.halo_hi = c.rr0 + RG == R;
+    FusedRow row[RG];
+    bool dirty = false;
+    const int xl = rg.xwin0 - 1, xr = rg.xwin0 + NT * 256;  // the columns next to the window (WIN)
+    const int gxp = c.lane < 32 ? xl : xr;
+    const bool col_in = (unsigned)gxp < (unsigned)g.W;
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        const int y = y0 - 1 + c.rr0 + i;  // this row
+        const bool yin = (unsigned)y < (unsigned)g.H;
+        row[i].row_in = xin && yin;        // this lane's cells exist
+        row[i].is_out_row = c.rr0 + i >= 1 && c.rr0 + i <= R - 2 && row[i].row_in;
+        // in-plane byte offsets (safe addresses for lanes / rows outside the grid)
+        row[i].boff = 4u * (xs + (unsigned)g.W * (unsigned)(yin ? y : 0));
+        row[i].pad_in = col_in && yin;
+        row[i].boff_pad = 4u * ((col_in ? (unsigned)gxp : 0u) + (unsigned)g.W * (unsigned)(yin ? y : 0));
+        dirty = dirty || !row[i].row_in;
+    }
+    const int yh = c.halo_lo ? y0 - 2 : y0 - 1 + R;  // the row just outside the workgroup
     const bool is_halo = c.halo_lo || c.halo_hi;
     c.halo_in = is_halo && xin && (unsigned)yh < (unsigned)g.H;
-    c.wave_clean = __builtin_amdgcn_ballot_w64(!c.row_in || (is_halo && !c.halo_in)) == 0ull;
-    c.lane_mask = c.row_in ? 0xFFFFFFFFu : 0u;
-    // in-plane byte offsets (safe addresses for lanes / rows outside the grid)
-    const unsigned xs = xin ? (unsigned)gx0 : 0u;
-    c.boff = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
     c.boff_h = 4u * (xs + (unsigned)g.W * (unsigned)(((unsigned)yh < (unsigned)g.H) ? yh : 0));
+    c.wave_clean = __builtin_amdgcn_ballot_w64(dirty || (is_halo && !c.halo_in)) == 0ull;
     // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
     c.xe = c.lane == 0 ? c.x0 - 1 : c.x0 + 4;
-    if (WIN) {
-        const int xl = rg.xwin0 - 1, xr = rg.xwin0 + NT * 256;  // the columns next to the window
-        const int gxp = c.lane < 32 ? xl : xr;
-        const bool col_in = (unsigned)gxp < (unsigned)g.W;
-        c.pad_in = col_in && (unsigned)y < (unsigned)g.H;
-        c.boff_pad = 4u * ((col_in ? (unsigned)gxp : 0u) +
-                           (unsigned)g.W * (unsigned)(((unsigned)y < (unsigned)g.H) ? y : 0));
-        c.pad_writer = (c.lane == 0 && tx == 0) || (c.lane == 63 && tx == NT - 1);
-        c.pad_x = c.lane == 0 ? -1 : NT * 256;
-    }
+    c.pad_writer = (c.lane == 0 && tx == 0) || (c.lane == 63 && tx == NT - 1);
+    c.pad_x = c.lane == 0 ? -1 : NT * 256;
 
     {   // DivEntry table
         FLUID_LDS float* tab = c.lds + 2 * 2 * R * RW;  // DivEntry {a, r} pairs
@@ -477,37 +552,57 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
         }
     }
     // pad cells of every LDS row: x = -1 and x = NT*256 read as p_oob (outside the grid)
-    for (int i = threadIdx.x; i < 2 * 2 * R * 2 * FUSED_PAD; i += FUSED_THREADS) {
-        const int side = i % (2 * FUSED_PAD), row = i / (2 * FUSED_PAD);
-        FLUID_LDS float* base = c.lds + row * RW;
+    for (int i = threadIdx.x; i < 2 * 2 * R * 2 * FUSED_PAD; i += G::THREADS) {
+        const int side = i % (2 * FUSED_PAD), r = i / (2 * FUSED_PAD);
+        FLUID_LDS float* base = c.lds + r * RW;
         base[side < FUSED_PAD ? side : RW - 2 * FUSED_PAD + side] = p_air;
     }
 
-    __syncthreads();  // the table is read before the first barrier of the march (div_pairs)
-
     // prologue: the state a step with ring phase 0 and zc = zb - 1 expects
     const float4 pa4 = make_float4(p_air, p_air, p_air, p_air);
-    FusedState st;
+    float4 h[2];
     int zc = c.zb - 1;  // plane of iterate j+1 formed in the coming step
-    st.j[0] = c.fix_j(ld_f4(pin + c.j_off(zc - 1), c.boff), c.row_in, zc - 1);
-    st.j[1] = c.fix_j(ld_f4(pin + c.j_off(zc), c.boff), c.row_in, zc);
-    st.j[2] = ld_f4(pin + c.j_off(zc + 1), c.boff);  // raw: fixed up by the first step
-    st.h[0] = ld_f4(pin + c.j_off(zc), c.boff_h);
-    st.s[0] = pa4;
-    st.s[1] = pa4;
-    st.b[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    st.m[1] = MASK_DRY4;
-    st.b[2] = ld_f4(rhs + c.m_off(zc), c.boff);
-    st.m[2] = ld_u32(mask + c.m_off(zc), c.boff >> 2);
-    for (int i = 0; i < 4; i++) st.dv[0].c[i] = st.dv[1].c[i] = make_float2(0.f, 0.f);
-    if (WIN) {
-        auto pad_at = [&](int lz) {
-            return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pin + c.j_off(lz)) +
-                                                   c.boff_pad);
-        };
-        st.padv[0] = pad_at(zc - 1);
-        st.padv[1] = pad_at(zc);
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        FusedRow& r = row[i];
+        r.j[0] = c.fix_j(ld_f4(pin + c.j_off(zc - 1), r.boff), r.row_in, zc - 1);
+        r.j[1] = c.fix_j(ld_f4(pin + c.j_off(zc), r.boff), r.row_in, zc);
+        r.j[2] = ld_f4(pin + c.j_off(zc + 1), r.boff);  // raw: fixed up by the first step
+        r.s[0] = pa4;
+        r.s[1] = pa4;
+        r.b[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.m[1] = MASK_DRY4;
+        r.b[2] = ld_f4(rhs + c.m_off(zc), r.boff);
+        r.m[2] = ld_u32(mask + c.m_off(zc), r.boff >> 2);
+        if (WIN) {
+            auto pad_at = [&](int lz) {
+                return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pin + c.j_off(lz)) +
+                                                       r.boff_pad);
+            };
+            r.padv[0] = pad_at(zc - 1);
+            r.padv[1] = pad_at(zc);
+        }
     }
+    h[0] = ld_f4(pin + c.j_off(zc), c.boff_h);
+    __syncthreads();  // pad cells are in place (the rows below overwrite two of them in windowed launches)
+    // what the first step expects behind its barrier: iterate j at plane zc, iterate j+1 (constants) at zc-1
+#pragma unroll
+    for (int i = 0; i < RG; i++) {
+        FusedRow& r = row[i];
+        if (WIN) r.padv[2] = *reinterpret_cast<const float*>(
+                     reinterpret_cast<const char*>(pin + c.j_off(zc + 1)) + r.boff_pad);
+        FLUID_LDS float* jrow = c.row_ptr(0, 0, c.rr0 + i);
+        FLUID_LDS float* srow = c.row_ptr(0, 1, c.rr0 + i);
+        lds_st4(jrow + c.x0, r.j[1]);
+        lds_st4(srow + c.x0, r.s[1]);
+        if (WIN) {
+            if (c.pad_writer) {
+                jrow[c.pad_x] = c.fix_pad(r.padv[1], r.pad_in, zc);
+                srow[c.pad_x] = c.fix_pad(r.padv[0], r.pad_in, zc - 1);
+            }
+        }
+    }
+    __syncthreads();
 
     const int steps = c.ze - c.zb + 2;  // iterate j+1 at planes zb-1 .. ze, iterate j+2 one behind
 #ifdef FLUID_FUSED_TRACE
@@ -516,13 +611,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step<NT, 0, WIN>(c, st, zc FLUID_TRACE_PASS);
+        fused_step<NT, RG, 0, WIN, KEEP>(c, row, h, zc FLUID_TRACE_PASS);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step<NT, 1, WIN>(c, st, zc + 1 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 1, WIN, KEEP>(c, row, h, zc + 1 FLUID_TRACE_PASS);
         if (k + 2 >= steps) break;
-        fused_step<NT, 2, WIN>(c, st, zc + 2 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 2, WIN, KEEP>(c, row, h, zc + 2 FLUID_TRACE_PASS);
         if (k + 3 >= steps) break;
-        fused_step<NT, 3, WIN>(c, st, zc + 3 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 3, WIN, KEEP>(c, row, h, zc + 3 FLUID_TRACE_PASS);
     }
 #ifdef FLUID_FUSED_TRACE
     {

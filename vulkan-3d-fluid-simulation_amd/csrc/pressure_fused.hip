@@ -35,11 +35,11 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
                                          part, part_lo, part_hi);
         }
     }
-    if (nt == 1) return launch_nt<1, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    if (nt == 1) return launch_rg<1, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
-    if (nt == 2) return launch_nt<2, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    if (nt == 2) return launch_rg<2, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
-    if (nt <= 4) return launch_nt<4, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+    if (nt <= 4) return launch_rg<4, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                      part_lo, part_hi);
     return hipErrorInvalidValue;
 }

@@ -69,24 +69,40 @@ static inline int cu_count() {
     return n;
 }
 
-template <int NT, bool WIN>
-static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+// rows per wavefront (FusedGeom) by x tiles per row, measured on MI355X (Jacobi iterations/s, RG = 1 / 2 / 3):
+//   NT = 1 (256^3)          27.3 k / 24.6 k / 43.7 k    R = 16 / 16 / 24 rows per workgroup
+//   NT = 2 (512^3)          5.60 k / 5.61 k / 5.22 k    R =  8 /  8 / 12 (RG = 3 spills at NT >= 2)
+//   NT = 4 (1024 x 1024 x 64)  9.3 k / 8.7 k / 11.9 k   R =  4 /  4 /  6: the halo rows are half / a third
+// FLUID_FUSED_RG = 1, 2 or 3 overrides it.
+static inline int fused_rows_per_wave(int nt) {
+    static const int forced = [] {
+        const char* e = getenv("FLUID_FUSED_RG");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 3) ? v : 0;
+    }();
+    if (forced) return forced;
+    return nt == 2 ? 2 : 3;
+}
+
+template <int NT, bool WIN, int RG, bool KEEP>
+static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                             float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
                             int part_lo, int part_hi) {
     // the dynamic-LDS limit is an attribute of the function on a device: once per instantiation and
     // device (a process may hold contexts on several)
+    using G = FusedGeom<NT, RG>;
     static bool attr_set[64] = {};
-    const size_t lds = fused_lds_bytes(NT);
+    const size_t lds = G::lds_bytes;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN, RG, KEEP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    constexpr int TY = FUSED_WAVES / NT - 2;
+    constexpr int TY = G::TY;
     FusedRange r = rg;
     int ty0 = 0, ty1 = (g.H + TY - 1) / TY;  // row tiles [ty0, ty1)
     // Sparse scene on a whole-grid context: launch only the tiles whose output rows / planes meet the
@@ -138,7 +154,8 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
         const char* e = getenv("FLUID_FUSED_XCD");
         return e == nullptr || atoi(e) != 0;
     }();
-    if (xcd_bands && by >= 16) {
+    // only where the bands come out even: the longest band sets the time (by / 8 row tiles each, rounded up)
+    if (xcd_bands && by >= 8 && 8 * ((by + 7) / 8) * 100 <= by * 104) {
         r.xcd_rows = by;
         r.xcd_nz = nz;
         grid = dim3(8 * ((by + 7) / 8) * nz, 1, 1);
@@ -147,9 +164,39 @@ static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
     bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
-    hipLaunchKernelGGL((k12_canon2<NT, WIN>), grid, dim3(FUSED_THREADS), lds, s, mask, rhs, pin, pout, pmid,
+    hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout, pmid,
                        bricks, bk, g, p_oob, zchunk, r);
     return hipSuccess;
+}
+
+// with / without the store of the odd iterate (the last pair of a loop keeps it)
+template <int NT, bool WIN, int RG>
+static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                            float* pout, float* pmid, const uint8_t* bricks, const GridK& g, float p_oob,
+                            const FusedRange& rg, const ActiveBox& box, int part, int part_lo, int part_hi) {
+    if (pmid)
+        return launch_keep<NT, WIN, RG, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                              part_lo, part_hi);
+    return launch_keep<NT, WIN, RG, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                           part_lo, part_hi);
+}
+
+// the instantiation for the configured rows per wavefront
+template <int NT, bool WIN>
+static hipError_t launch_rg(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                            float* pout, float* pmid, const uint8_t* bricks, const GridK& g, float p_oob,
+                            const FusedRange& rg, const ActiveBox& box, int part, int part_lo, int part_hi) {
+    switch (fused_rows_per_wave(NT)) {
+        case 1:
+            return launch_nt<NT, WIN, 1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                         part_lo, part_hi);
+        case 3:
+            return launch_nt<NT, WIN, 3>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                         part_lo, part_hi);
+        default:
+            return launch_nt<NT, WIN, 2>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                         part_lo, part_hi);
+    }
 }
 
 }  // namespace fluid

@@ -11,10 +11,10 @@ hipError_t k12_launch_canon2_win(hipStream_t s, int nt_window, const uint8_t* ma
                                  const GridK& g, float p_oob, const FusedRange& rg,
                                  const ActiveBox& box, int part, int part_lo, int part_hi) {
     if (nt_window == 1)
-        return launch_nt<1, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+        return launch_rg<1, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                   part_lo, part_hi);
     if (nt_window == 2)
-        return launch_nt<2, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+        return launch_rg<2, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                   part_lo, part_hi);
     return hipErrorInvalidValue;
 }
