@@ -55,10 +55,28 @@ def parse_args():
     return ap.parse_args()
 
 
+FUSED_KERNEL_SOURCES = ["kernels_pressure_fused.h", "pressure_fused_launch.h", "pressure_fused.hip",
+                        "pressure_common.h"]
+
+
+def kernel_sources_sha16():
+    """What a recorded counter figure is valid for: the sources of the Jacobi loop kernel and of its
+    launch shaping (tools/make_pmc_traffic.py stamps the same hash into profiles/*/pmc_traffic_*.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in FUSED_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "vulkan-3d-fluid-simulation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def recorded_traffic(kernel, size):
-    """HBM bytes per launch of `kernel` from the PMC passes kept under profiles/ (rocprofv3 --pmc cannot
-    run inside this process): (bytes, source) for this kernel and grid, else (None, None)."""
+    """HBM-side bytes per launch of `kernel` from the PMC passes kept under profiles/ (rocprofv3 --pmc
+    cannot run inside this process): (bytes, source) for this kernel and grid — but only from a record
+    stamped with the hash of the kernel sources as they are now; a stale record gives (None, why)."""
     import glob
+    want = kernel_sources_sha16()
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic_*.json")), reverse=True):
         try:
             with open(path) as f:
@@ -66,8 +84,11 @@ def recorded_traffic(kernel, size):
         except (OSError, ValueError):
             continue
         if rec.get("kernel") == kernel and list(rec.get("grid", [])) == list(size):
-            return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
-    return None, None
+            if rec.get("kernel_sources_sha16") == want:
+                return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+            stale = (f"{os.path.relpath(path, ROOT)} was recorded for kernel sources "
+                     f"{rec.get('kernel_sources_sha16')}, the build has {want}")
+    return None, stale
 
 
 def grid_dims(grid):
@@ -225,20 +246,62 @@ def full_step_bench(size, iters, steps, device):
             eng.run_step()
         eng.sync()
         sections = {k: round(v[0] / tsteps, 4) for k, v in eng.section_times().items() if v[1]}
-    cells = size[0] * size[1] * size[2]
-    step_bytes = (293.0 + 13.0 * iters) * cells + 48.0 * cap   # SURVEY.md §8d, reference layout
     return {
-        "workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi iters",
+        "workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi iters "
+                    f"(sparse: {round(100 * quiet)} % of the bricks are skipped, so this is a rate, not a "
+                    "roofline statement: see full_step_dense)",
         "steps_per_sec": steps / dt,
         "ms_per_step": 1e3 * dt / steps,
         "steps": steps,
-        "algorithmic_GBps": step_bytes * steps / dt / 1e9,
-        "frac_of_hbm_peak": step_bytes * steps / dt / 1e9 / HBM_PEAK_GBS,
         "quiet_brick_fraction": round(quiet, 4),
         "section_ms_per_step": sections,
         "note": ("grouped passes: 04/05 = the two type scans of 04+05, 07 = 07+08, 09 = 09+10+11; "
                  "12_solve_pressure includes its prepare / import / export passes"),
     }
+
+
+def full_step_dense_bench(n, iters, steps, device):
+    """Full simulation steps/sec (01a...14) on a tank filled to the brim: every section works on nearly
+    every cell and nothing is skipped, so the algorithmic bytes of SURVEY.md 8d (reference layout:
+    293 + 13 x iterations B/cell, 48 B/particle) over the step time IS a roofline statement."""
+    import fluid_amd
+    from fluid_amd import engine as E
+
+    size = (n - 4.0,) * 3
+    res = tuple(int(round(2.0 * v)) for v in size)
+    cap = res[0] * res[1] * res[2]
+    p = fluid_amd.default_params(n, n, n, cap)
+    p.particle_spawn_cube_resolution[:] = res
+    p.particle_spawn_cube_volume = cap
+    p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
+    p.particle_spawn_cube_size[:] = size
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters, device=device) as eng:
+        eng.run_init()
+        for _ in range(2):
+            eng.run_step()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run_step()
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        quiet = eng.get_stat(E.STAT_QUIET_BRICKS)
+        eng.enable_timing(True)
+        eng.reset_timing()
+        for _ in range(2):
+            eng.run_step()
+        eng.sync()
+        sections = {k: round(v[0] / 2, 4) for k, v in eng.section_times().items() if v[1]}
+    cells = n ** 3
+    step_bytes = (293.0 + 13.0 * iters) * cells + 48.0 * cap   # SURVEY.md 8d, reference layout
+    return {"workload": f"full tank {n}^3, {cap} particles (8 per cell), {iters} Jacobi iters",
+            "steps_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps,
+            "algorithmic_bytes_per_step": step_bytes,
+            "algorithmic_GBps": step_bytes / dt / 1e9,
+            "frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            "quiet_bricks": quiet,
+            "section_ms_per_step": sections,
+            "particles_per_sec": cap / dt}
 
 
 def surface_prep_bench(n, iters, device):
@@ -451,16 +514,25 @@ def main():
                    "grid": [w, h, d], "jacobi_iterations": args.iters, "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     # the physical figure: counter bytes per launch over the launch time
+                     "achieved_traffic": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                     "frac_traffic": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "traffic_over_single_pass_min": (traffic / (JACOBI_BYTES_PER_CELL * cells))
+                     if traffic else None,
                      "traffic_source": traffic_source,
+                     "kernel_sources_sha16": kernel_sources_sha16(),
                      "kernel": kernel_name,
                      "sweeps_per_launch": sweeps_per_launch,
                      "launch_ms": launch_ms, "ms_per_sweep": kernel_ms,
                      "algorithmic_bytes_per_launch":
                          JACOBI_BYTES_PER_CELL * cells * sweeps_per_launch,
-                     "note": ("temporal blocking: each launch applies two Jacobi sweeps while "
-                              "streaming the grid once, so the algorithmic 13 B/cell/sweep figure "
-                              "can exceed the HBM roofline (SURVEY.md §8d allows this); measured "
-                              "HBM traffic per launch is in profiles/") if fused else ""},
+                     "note": ("frac = ALGORITHMIC bytes (13 B/cell/sweep x the sweeps of a launch) / launch "
+                              "time / peak: each launch applies two Jacobi sweeps while streaming the grid "
+                              "once (temporal blocking), so it can exceed 1 (SURVEY.md 8d allows this).  "
+                              "frac_traffic = bytes the L2s requested from the fabric (TCC_EA0_RDREQ x 128 B "
+                              "+ WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/) / launch time / "
+                              "peak; traffic_over_single_pass_min = those bytes / one 13 B/cell pass") if fused
+                     else ""},
         "residual_after_loop": {"max_abs": res_max,
                                 "rms": (res_sumsq / max(res_cells, 1)) ** 0.5,
                                 "water_cells": res_cells,
@@ -480,6 +552,10 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     if not args.no_full_step:
         out["full_step"] = full_step_bench(size, args.iters, args.full_step_steps, local_rank)
+        try:
+            out["full_step_dense"] = full_step_dense_bench(w, args.iters, 3, local_rank)
+        except Exception as exc:  # secondary figure (needs 16 B x 8 particles per cell of HBM)
+            out["full_step_dense"] = {"error": f"{type(exc).__name__}: {exc}"}
     if not args.no_surface and not args.no_full_step:
         try:
             out["surface_prep"] = surface_prep_bench(128, 80, local_rank)

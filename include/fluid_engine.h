@@ -432,6 +432,36 @@ int fluid_particles_collect(fluid_ctx* ctx, int reset_lists, uint32_t counts[2],
 int fluid_particles_adopt_received(fluid_ctx* ctx, uint32_t from_below, uint32_t from_above,
                                    uint32_t forwarded[2]);
 
+/* A step driven section by section from outside (what a Z-slab context needs: ghost planes travel between
+ * the sections; include/fluid_slab.h does it), with the skipping fluid_run_step does on a whole-grid context:
+ *   fluid_step_begin            the calls up to fluid_step_end run the step list 01a ... 14 once, in order
+ *                               (fluid_run_section, fluid_run_section_group, the explicit pressure loop);
+ *                               bricks far from the water are skipped as in fluid_run_step, and ghost-plane
+ *                               exchanges do not count as writes from outside.  section_list = 1: the
+ *                               caller runs one section per call (no grouped passes): nothing is skipped
+ *   fluid_step_build_activity   after 06: the activity bricks of the new CELL_TYPES (one byte per 256 x 4 x 16
+ *                               cells).  A brick is skipped when neither it nor any of its 26 neighbours has
+ *                               held water for three steps — across a slab face the neighbours are the other
+ *                               slab's edge layer: exchange fluid_activity_layer_ptr(0 / 1) = this context's
+ *                               bottom / top layer with (2 / 3) = the layer received from below / above
+ *                               (bytes = 0: this step does not skip, nothing to exchange).  Without the
+ *                               exchange the bricks at a shared face are never skipped.
+ *   fluid_step_status           after 07 (+ 08): words[0] = the halo-violation flag (read and cleared, as
+ *                               fluid_slab_status), words[1] = 1 if the box of this context's water is known,
+ *                               then [2] = bricks with water, rows [3], [4)), cells [5], [6)) along x.
+ *                               Synchronises the stream once (the reduction the sampler protocol needs anyway).
+ *   fluid_step_set_box          the launches of the pressure loop cover only these rows and — where the water
+ *                               spans at most two 256-cell columns — this x window: the UNION of this context's
+ *                               box with its Z-neighbours' (their water is what the ghost planes hold);
+ *                               own_bricks = 0: this context has no water, its launches are skipped. */
+int fluid_step_begin(fluid_ctx* ctx, int section_list);
+int fluid_step_end(fluid_ctx* ctx);
+int fluid_step_build_activity(fluid_ctx* ctx);
+int fluid_activity_layer_ptr(fluid_ctx* ctx, int which, void** device_ptr, uint64_t* bytes);
+int fluid_step_status(fluid_ctx* ctx, uint32_t words[8]);
+int fluid_step_set_box(fluid_ctx* ctx, int valid, uint32_t own_bricks, uint32_t y_lo, uint32_t y_hi,
+                       uint32_t x_lo, uint32_t x_hi);
+
 /* The velocity sampler of 07_advect on a Z slab (particles and back-traces are never
  * clamped, advect.comp:63-78).  A back-trace reaches floor(|v.z| * dt) + 1 planes from its cell, so how
  * many ghost planes of VELOCITIES_1 07 needs depends on the flow.  The protocol the slab driver

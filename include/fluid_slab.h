@@ -106,6 +106,15 @@ typedef struct fluid_slab_backend {
     int (*collect)(void* user, int reset_lists, uint32_t counts[2], uint32_t* left_behind);
     int (*adopt_received)(void* user, uint32_t from_below, uint32_t from_above, uint32_t forwarded[2]);
     int (*sync)(void* user);                                                 /* fluid_sync              */
+    /* a step with the engine's skipping (fluid_step_*); a backend without it answers bytes = 0 for the
+     * activity layers and words[1] = 0 (box unknown) */
+    int (*step_begin)(void* user, int section_list);
+    int (*step_end)(void* user);
+    int (*build_activity)(void* user);
+    int (*activity_layer)(void* user, int which, void** ptr, uint64_t* bytes);
+    int (*step_status)(void* user, uint32_t words[8]);
+    int (*set_box)(void* user, int valid, uint32_t own_bricks, uint32_t y_lo, uint32_t y_hi, uint32_t x_lo,
+                   uint32_t x_hi);
 } fluid_slab_backend;
 
 /* ---- creation ---------------------------------------------------------------------------------------- */

@@ -82,7 +82,8 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
         ("pressures_1", E.PRESSURES_1), ("pressures_2", E.PRESSURES_2),
         ("divergences", E.DIVERGENCES), ("particle_densities", E.PARTICLE_DENSITIES_IMG)]}
     out["particles"] = sim.gather_particles()
-    t = torch.tensor([sim.stat(i) for i in range(8)], dtype=torch.int64)
+    t = torch.tensor([sim.stat(i) for i in range(8)] + [sim.engine.get_stat(E.STAT_QUIET_BRICKS)],
+                     dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         np.savez(os.path.join(out_dir, "result.npz"), stats=t.numpy(), **out)
@@ -129,6 +130,22 @@ def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, inte
     assert np.any(st.cell_types[face - 1] == 2) and np.any(st.cell_types[face] == 2)
     assert int(got["stats"][S.STAT_MIGRATED]) > 0
     assert int(got["stats"][S.STAT_SAMPLER_RERUNS]) == 0
+
+
+@pytest.mark.parametrize("world,size", [(2, (64, 64, 96)), (3, (256, 48, 96))])
+def test_slab_simulation_skips_quiet_bricks_like_the_single_gpu_step(world, size, tmp_path):
+    """Ten steps of a block of water that straddles the slab faces in a tank with room around it: from the
+    third step on every slab skips the bricks far from the water (quiet_bricks.h) — across a face by the
+    neighbouring slab's edge layer of activity bricks, exchanged after 06 — and launches its pressure loop
+    over the union of its box with its neighbours'.  Bit-identical to the oracle, and bricks WERE skipped."""
+    import torch.multiprocessing as mp
+
+    iters, steps = 6, 10
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, True, str(tmp_path), False),
+                       nprocs=world, join=True, start_method="spawn")
+    got = np.load(os.path.join(str(tmp_path), "result.npz"))
+    _check(got, world, size, iters, steps)
+    assert int(got["stats"][8]) > 0    # FLUID_STAT_QUIET_BRICKS of the last step, max over the ranks
 
 
 @pytest.mark.parametrize("world,size,fast,expect_wide", [

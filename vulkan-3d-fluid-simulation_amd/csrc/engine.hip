@@ -105,6 +105,12 @@ struct fluid_ctx {
     bool early_in_use = false;    // inside fluid_run_step, between 01 and 06
     bool early_wanted = false;    // the running 01 pass also derives the one-step test from its marks
     bool pbricks_valid = false;   // pbricks() marks every brick in which the last 01 counted a particle
+    // a step driven section by section from outside (fluid_step_begin / _end: the Z-slab driver), with the
+    // skipping fluid_run_step does
+    bool driver_step = false, ds_quiet = false, ds_early = false;
+    uint64_t ghost_bricks_offset = 0;  // the neighbouring slabs' edge layers of the activity bricks: 2 x nbx*nby
+    bool ghost_bricks_valid = false;   // ... as exchanged in this step
+    bool box_from_driver = false;      // c->box was set by fluid_step_set_box (union with the neighbours')
     bool quiet_valid = false;     // the streaks describe the images (nothing wrote them from outside)
     bool quiet_in_use = false;    // inside fluid_run_step, between 06 and 13: kernels may skip
     uint64_t work_offset[3] = {0, 0, 0};  // working pressure buffers, Dl + 2*LOOP_GHOST planes each
@@ -176,6 +182,20 @@ struct fluid_ctx {
     const uint8_t* quiet_or_null() const { return quiet_in_use ? quiet() : nullptr; }
     uint8_t* early() const { return arena + early_offset; }
     uint8_t* pbricks() const { return arena + pbricks_offset; }
+    uint8_t* ghost_bricks(int face) const {
+        return arena + ghost_bricks_offset + (uint64_t)face * (active_bytes / (uint64_t)std::max(1, nbz()));
+    }
+    int nbz() const { return (g.Dl + 15) / 16; }
+    // how the quiet / early tests see the brick layers beyond this context's faces
+    BrickEdges brick_edges(bool ghosts_usable) const {
+        BrickEdges e;
+        const bool nb[2] = {g.z0 > 0, g.z0 + g.Dl < g.Dg};
+        for (int f = 0; f < 2; f++) {
+            e.ghost[f] = ghost_bricks(f);
+            e.kind[f] = !nb[f] ? EDGE_NONE : (ghosts_usable && ghost_bricks_valid ? EDGE_GHOST : EDGE_UNKNOWN);
+        }
+        return e;
+    }
     const uint8_t* early_or_null() const { return early_in_use ? early() : nullptr; }
     uint32_t* flags() const { return reinterpret_cast<uint32_t*>(arena + flags_offset); }
     // list 0 / 1: leavers to send down / up; 2 / 3: received from the neighbour below / above
@@ -283,7 +303,7 @@ struct Layout {
     uint64_t particles_offset, particles_bytes;
     uint64_t mask_offset, rhs_offset, active_offset, active_bytes, quiet_offset, early_offset,
         pbricks_offset, work_offset[3];
-    uint64_t flags_offset, leavers_offset;
+    uint64_t flags_offset, leavers_offset, ghost_bricks_offset;
     uint32_t leavers_capacity;
     uint64_t surf_offset[4], surf_cells;
     uint64_t total;
@@ -340,6 +360,8 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     }
     L.flags_offset = off;
     off = align_up(off + 256, kAlign);
+    L.ghost_bricks_offset = off;
+    off = align_up(off + 2 * L.active_bytes, kAlign);  // two layers would do; bytes are cheap here
     // Four lists (send down / up, received from below / above) of capacity / 16 entries each, at least
     // 64 Ki: 8 bytes per particle slot.  More leavers than that in one step take more hand-over rounds
     // (fluid_particles_collect leaves them in place and says so), they are never dropped.
@@ -824,7 +846,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             c->pbricks_valid = true;
             if (c->early_wanted)
                 hipLaunchKernelGGL(k_update_early_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
-                                   c->bricks(), c->pbricks(), c->early(), bk);
+                                   c->bricks(), c->pbricks(), c->early(), bk, c->brick_edges(false));
             break;
         }
         case FLUID_SEC_01_UPDATE_DENSITIES: {
@@ -1221,6 +1243,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->pbricks_offset = L.pbricks_offset;
     for (int i = 0; i < 3; i++) c->work_offset[i] = L.work_offset[i];
     c->flags_offset = L.flags_offset;
+    c->ghost_bricks_offset = L.ghost_bricks_offset;
     c->leavers_offset = L.leavers_offset;
     c->leavers_capacity = L.leavers_capacity;
     c->arena_bytes = L.total;
@@ -1450,10 +1473,15 @@ int fluid_set_option(fluid_ctx* c, int option, int64_t value) {
     return FLUID_OK;
 }
 
+static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool whole_step);
+
 int fluid_run_section(fluid_ctx* c, int section_id) {
-    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->driver_step && section_id >= FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES &&
+        section_id <= FLUID_SEC_14_PARTICLES && section_id != FLUID_SEC_12_SOLVE_PRESSURE)
+        return run_step_slice(c, section_id, 1, true, false);  // a step driven from outside: with its skipping
+    c->quiet_valid = false;  // a write from outside a step (quiet_bricks.h)
     return timed_section(c, section_id);
 }
 
@@ -1702,38 +1730,38 @@ static int run_surface_prep(fluid_ctx* c) {
 // Entries [first, first + count) of SimulationStepSections (fluid_flow_sections.h:163-338; the ids are
 // consecutive in list order).  `grouped`: sections 04+05, 07+08 and 09+10+11 run as the grouped passes
 // of kernels_step_fused.h, each timed under the id of the section it stands in for.
-static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool whole_step = false) {
+static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool whole_step) {
     const bool group = grouped && c->g.W % 4 == 0;
     const int end = first + count;
     // quiet bricks (quiet_bricks.h): only inside a whole grouped step on a whole-grid context whose
     // pressure loop runs on the working buffers (that is where the activity bricks come from)
-    const bool quiet = whole_step && group && !c->is_slab && fast_loop_possible(c) &&
-                       c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT &&
-                       c->opt[FLUID_OPT_QUIET_BRICKS] == 0;
-    c->quiet_in_use = false;
+    const bool quiet = c->driver_step
+                           ? c->ds_quiet
+                           : (whole_step && group && !c->is_slab && fast_loop_possible(c) &&
+                              c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT &&
+                              c->opt[FLUID_OPT_QUIET_BRICKS] == 0);
     // the one-step test for the sections before 06 needs the previous step's water map in bricks():
     // nothing may have written the images since that step (quiet_valid still set)
-    const bool early = quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid &&
-                       first == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES;
-    c->early_in_use = false;
+    const bool early = c->driver_step ? c->ds_early
+                                      : (quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid &&
+                                         first == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES);
+    if (!c->driver_step) c->quiet_in_use = c->early_in_use = false;  // else they carry over between calls
     for (int s = first; s < end;) {
         int rc, used = 1;
         if (early && s == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES) {
             rc = timed_section(c, s, STEP_01A_CLEAR_WHERE_PARTICLES_WERE);
-            c->early_wanted = true;
-            if (rc == FLUID_OK)
-                rc = timed_section(c, FLUID_SEC_01_UPDATE_DENSITIES, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
-            c->early_wanted = false;
             if (rc) return rc;
-            c->early_in_use = true;
-            s += 2;
+            s += 1;
             continue;
         }
         if (quiet && s == FLUID_SEC_01_UPDATE_DENSITIES) {
-            // not skipping yet (first step, or something wrote the images), but the next step's 01a clears
-            // only the bricks this pass marks
+            // the pass marks the bricks it counts particles in: the next step's 01a clears only those, and —
+            // when this step may skip already — the one-step test of 02 ... 05 is derived from the marks
+            c->early_wanted = early;
             rc = timed_section(c, s, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
+            c->early_wanted = false;
             if (rc) return rc;
+            c->early_in_use = early;
             s += 1;
             continue;
         }
@@ -1749,7 +1777,7 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
             const int nb = (int)c->active_bytes;
             HIP_TRY(c, hipMemsetAsync(c->flags() + 9, 0, 4, c->stream));
             hipLaunchKernelGGL(k_update_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
-                               c->bricks(), c->quiet(), bk, c->flags() + 9);
+                               c->bricks(), c->quiet(), bk, c->flags() + 9, c->brick_edges(true));
             HIP_TRY(c, hipGetLastError());
             c->quiet_valid = true;
             c->quiet_in_use = true;
@@ -1779,7 +1807,7 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
         if (s == FLUID_SEC_13_FIX_DIVERGENCE) c->quiet_in_use = false;
         s += used;
     }
-    c->quiet_in_use = c->early_in_use = false;
+    if (!c->driver_step) c->quiet_in_use = c->early_in_use = false;
     return FLUID_OK;
 }
 
@@ -1795,7 +1823,7 @@ int fluid_run_step(fluid_ctx* c) {
 }
 
 int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) {
-    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
+    if (c && !c->driver_step) c->quiet_valid = false;  // a write from outside a step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (first_section_id < FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES ||
@@ -1815,7 +1843,100 @@ int fluid_run_section_group(fluid_ctx* c, int first_section_id, uint32_t count) 
             return slab_unsupported(c, "this slice of the step list in one call (only 04+05, 07+08 "
                                        "and, for fluid_size.x % 4 == 0, 09+10+11)");
     }
-    return run_step_slice(c, first_section_id, (int)count, true);
+    return run_step_slice(c, first_section_id, (int)count, true, false);
+}
+
+// ---- a step driven section by section from outside (the Z-slab driver), with fluid_run_step's skipping ----
+int fluid_step_begin(fluid_ctx* c, int section_list) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (c->driver_step) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_step_begin twice");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->driver_step = true;
+    // skipping goes with the grouped passes (as in fluid_run_step): not when the caller runs the section list
+    c->ds_quiet = !section_list && c->g.W % 4 == 0 && c->opt[FLUID_OPT_STEP_FUSION] == 0 &&
+                  fast_loop_possible(c) &&
+                  c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT && c->opt[FLUID_OPT_QUIET_BRICKS] == 0;
+    c->ds_early = c->ds_quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid;
+    c->quiet_in_use = c->early_in_use = false;
+    c->ghost_bricks_valid = false;
+    c->box_from_driver = false;
+    return FLUID_OK;
+}
+
+int fluid_step_end(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    c->driver_step = false;
+    c->quiet_in_use = c->early_in_use = false;
+    return FLUID_OK;
+}
+
+int fluid_step_build_activity(fluid_ctx* c) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!c->driver_step) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_step_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->ds_quiet) return FLUID_OK;
+    return ensure_prepared(c, true);  // mask + activity bricks of the CELL_TYPES 06 just made
+}
+
+int fluid_activity_layer_ptr(fluid_ctx* c, int which, void** device_ptr, uint64_t* bytes) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!device_ptr || !bytes) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (which < 0 || which > 3) return c->fail(FLUID_ERR_INVALID_ARG, "activity layer %d", which);
+    int nbx, nby, nbz;
+    k12_brick_dims(c->g.W, c->g.H, c->g.Dl, nbx, nby, nbz);
+    const uint64_t layer = (uint64_t)nbx * nby;
+    *bytes = c->ds_quiet || !c->driver_step ? layer : 0;  // nothing to exchange when the step does not skip
+    switch (which) {
+        case 0: *device_ptr = c->bricks(); break;                                  // own bottom layer
+        case 1: *device_ptr = c->bricks() + (uint64_t)(nbz - 1) * layer; break;    // own top layer
+        case 2: *device_ptr = c->arena + c->ghost_bricks_offset; break;            // from below
+        default: *device_ptr = c->arena + c->ghost_bricks_offset + layer; break;   // from above
+    }
+    if (which >= 2) c->ghost_bricks_valid = true;  // the caller is about to fill them
+    return FLUID_OK;
+}
+
+int fluid_step_status(fluid_ctx* c, uint32_t words[8]) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!words) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t v = 0;
+    HIP_TRY(c, hipMemcpyAsync(&v, c->flags(), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // also lands the brick summary of ensure_prepared
+    if (v) HIP_TRY(c, hipMemsetAsync(c->flags(), 0, 4, c->stream));
+    memset(words, 0, 8 * sizeof(uint32_t));
+    words[0] = v;
+    if (c->box_pending && c->brick_count_host) {
+        c->box_pending = false;
+        const uint32_t* h = c->brick_count_host;
+        int bx, by, bz;
+        k12_brick_cells(bx, by, bz);
+        words[1] = 1;                                             // the box below is known
+        words[2] = h[0];                                          // bricks with water
+        words[3] = h[1] * (uint32_t)by;                           // rows [3], [4)
+        words[4] = std::min<uint32_t>(h[2] * (uint32_t)by, (uint32_t)c->g.H);
+        words[5] = h[5];                                          // cells [5], [6) along x
+        words[6] = std::min<uint32_t>(h[6], (uint32_t)c->g.W);
+        c->box.z_lo = (int)h[3] * bz;                             // local planes: this context's own
+        c->box.z_hi = std::min((int)h[4] * bz, c->g.Dl);
+        c->box.fraction = (float)h[0] / (float)c->active_bytes;
+    }
+    return FLUID_OK;
+}
+
+int fluid_step_set_box(fluid_ctx* c, int valid, uint32_t own_bricks, uint32_t y_lo, uint32_t y_hi,
+                       uint32_t x_lo, uint32_t x_hi) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    c->box.valid = valid != 0;
+    c->box_from_driver = valid != 0;
+    if (!valid) return FLUID_OK;
+    // own_bricks == 0: this context has no water cell, its launches write nothing (an empty y range says so)
+    c->box.y_lo = own_bricks ? (int)y_lo : 0;
+    c->box.y_hi = own_bricks ? (int)std::min<uint32_t>(y_hi, (uint32_t)c->g.H) : 0;
+    c->box.x_lo = (int)x_lo;
+    c->box.x_hi = (int)std::min<uint32_t>(x_hi, (uint32_t)c->g.W);
+    // z: this context's own planes with water (fluid_step_status left them in the box)
+    return FLUID_OK;
 }
 
 int fluid_sync(fluid_ctx* c) {
@@ -1887,7 +2008,7 @@ int fluid_notify_image_written(fluid_ctx* c, int image_id) {
 }
 
 int fluid_notify_ghost_planes_written(fluid_ctx* c, int image_id) {
-    if (c) c->quiet_valid = false;  // a write from outside fluid_run_step (quiet_bricks.h)
+    if (c && !c->driver_step) c->quiet_valid = false;  // a write from outside a step (quiet_bricks.h)
     if (!c) return FLUID_ERR_INVALID_ARG;
     int rc = check_image(c, image_id);
     if (rc) return rc;
@@ -2063,7 +2184,7 @@ int fluid_sampler_wide_plane_ptr(fluid_ctx* c, int32_t plane, void** device_ptr,
 }
 
 int fluid_run_advect_wide(fluid_ctx* c, int with_forces) {
-    if (c) c->quiet_valid = false;
+    if (c) c->quiet_valid = false;  // the pass below processes every cell: the streaks start over
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->wide) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_sampler_wide_begin first");
     HIP_TRY(c, hipSetDevice(c->device));

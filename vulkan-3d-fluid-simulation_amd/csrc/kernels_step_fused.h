@@ -31,21 +31,43 @@
 namespace fluid {
 
 // ---- quiet bricks (quiet_bricks.h) ----------------------------------------------------------------
-__global__ void k_update_quiet(const uint8_t* __restrict__ active, uint8_t* __restrict__ streak,
-                               BrickK bk, uint32_t* __restrict__ quiet_count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = bk.nbx * bk.nby * bk.nbz;
-    if (i >= n) return;
-    const int bx = i % bk.nbx, by = (i / bk.nbx) % bk.nby, bz = i / (bk.nbx * bk.nby);
+// A Z-slab context does not hold the bricks beyond its faces.  `edge`: for each face (0 = below, 1 =
+// above) how to treat them: EDGE_NONE = domain face, nothing there; EDGE_GHOST = the neighbouring slab's
+// edge layer of the same map is in ghost[face] (one byte per brick column, exchanged by the caller);
+// EDGE_UNKNOWN = a neighbour exists but its layer is not known: counts as holding water.
+enum : int { EDGE_NONE = 0, EDGE_GHOST = 1, EDGE_UNKNOWN = 2 };
+struct BrickEdges {
+    const uint8_t* ghost[2];
+    int kind[2];
+};
+__device__ __forceinline__ uint32_t brick_neighbourhood(const uint8_t* __restrict__ a,
+                                                        const uint8_t* __restrict__ b, const BrickK& bk,
+                                                        const BrickEdges& e, int bx, int by, int bz) {
     uint32_t any = 0;
     for (int dz = -1; dz <= 1; dz++)
         for (int dy = -1; dy <= 1; dy++)
             for (int dx = -1; dx <= 1; dx++) {
                 const int x = bx + dx, y = by + dy, z = bz + dz;
-                if ((unsigned)x < (unsigned)bk.nbx && (unsigned)y < (unsigned)bk.nby &&
-                    (unsigned)z < (unsigned)bk.nbz)
-                    any |= active[brick_index(bk, x, y, z)];
+                if ((unsigned)x >= (unsigned)bk.nbx || (unsigned)y >= (unsigned)bk.nby) continue;
+                if ((unsigned)z < (unsigned)bk.nbz) {
+                    const int j = brick_index(bk, x, y, z);
+                    any |= (uint32_t)a[j] | (b ? (uint32_t)b[j] : 0u);
+                } else {
+                    const int face = z < 0 ? 0 : 1;
+                    if (e.kind[face] == EDGE_UNKNOWN) any |= 1u;
+                    if (e.kind[face] == EDGE_GHOST) any |= (uint32_t)e.ghost[face][x + bk.nbx * y];
+                }
             }
+    return any;
+}
+
+__global__ void k_update_quiet(const uint8_t* __restrict__ active, uint8_t* __restrict__ streak,
+                               BrickK bk, uint32_t* __restrict__ quiet_count, BrickEdges edges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = bk.nbx * bk.nby * bk.nbz;
+    if (i >= n) return;
+    const int bx = i % bk.nbx, by = (i / bk.nbx) % bk.nby, bz = i / (bk.nbx * bk.nby);
+    const uint32_t any = brick_neighbourhood(active, nullptr, bk, edges, bx, by, bz);
     const uint32_t s = streak[i];
     const uint32_t now = any ? 0u : (s < 255u ? s + 1u : 255u);
     streak[i] = (uint8_t)now;
@@ -54,26 +76,16 @@ __global__ void k_update_quiet(const uint8_t* __restrict__ active, uint8_t* __re
 
 
 // early[b] = 255 where brick b and its 26 neighbours neither held water after the previous step (`old_water`)
-// nor receive a particle in this one (`particle_bricks`), else 0 (quiet_bricks.h)
+// nor receive a particle in this one (`particle_bricks`), else 0 (quiet_bricks.h).  The particle marks of a
+// neighbouring slab are not exchanged: its edge layer counts as marked (edges.kind = EDGE_UNKNOWN there).
 __global__ void k_update_early_quiet(const uint8_t* __restrict__ old_water,
                                      const uint8_t* __restrict__ particle_bricks,
-                                     uint8_t* __restrict__ early, BrickK bk) {
+                                     uint8_t* __restrict__ early, BrickK bk, BrickEdges edges) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = bk.nbx * bk.nby * bk.nbz;
     if (i >= n) return;
     const int bx = i % bk.nbx, by = (i / bk.nbx) % bk.nby, bz = i / (bk.nbx * bk.nby);
-    uint32_t any = 0;
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++)
-            for (int dx = -1; dx <= 1; dx++) {
-                const int x = bx + dx, y = by + dy, z = bz + dz;
-                if ((unsigned)x < (unsigned)bk.nbx && (unsigned)y < (unsigned)bk.nby &&
-                    (unsigned)z < (unsigned)bk.nbz) {
-                    const int j = brick_index(bk, x, y, z);
-                    any |= (uint32_t)old_water[j] | (uint32_t)particle_bricks[j];
-                }
-            }
-    early[i] = any ? 0 : 255;
+    early[i] = brick_neighbourhood(old_water, particle_bricks, bk, edges, bx, by, bz) ? 0 : 255;
 }
 
 // 01a inside fluid_run_step: the density image is non-zero only in the cells where the previous step's

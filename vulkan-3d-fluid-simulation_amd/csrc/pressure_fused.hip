@@ -24,9 +24,9 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.xwin0 = 0;
     rg.xcd_rows = rg.xcd_nz = 0;
     const int nt = (g.W + 255) / 256;
-    // Sparse scene, whole-grid context: if the bricks that hold water span one or two 256-cell columns of
+    // Sparse scene: if the bricks that hold water (on a Z slab: here and in the neighbouring slabs) span one or two 256-cell columns of
     // a wider grid, launch over that x window only (fewer lanes, more rows per workgroup).
-    if (box.valid && rg.zout_lo == 0 && rg.zout_hi == g.Dl && box.x_hi > box.x_lo) {
+    if (box.valid && box.x_hi > box.x_lo) {
         const int x0 = box.x_lo & ~31;  // 128-byte aligned rows
         const int ntw = (box.x_hi - x0 + 255) / 256;
         if ((ntw == 1 || ntw == 2) && ntw < nt) {

@@ -105,15 +105,24 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     constexpr int TY = G::TY;
     FusedRange r = rg;
     int ty0 = 0, ty1 = (g.H + TY - 1) / TY;  // row tiles [ty0, ty1)
-    // Sparse scene on a whole-grid context: launch only the tiles whose output rows / planes meet the
-    // bricks that hold water.  The others would leave at once (no water cell to write), but a
-    // workgroup of 16 wavefronts that starts and leaves still costs a slot on a CU.
-    if (box.valid && rg.zout_lo == 0 && rg.zout_hi == g.Dl) {
+    // Sparse scene: launch only the tiles whose output rows / planes meet the bricks that hold water.  The
+    // others would leave at once (no water cell to write), but a workgroup that starts and leaves still costs
+    // a slot on a CU.  On a Z slab the box is the union with the neighbouring slabs' (engine.hip:
+    // fluid_step_set_box) and the plane range stays what the halo depth asks for.
+    if (box.valid) {
         if (box.y_hi <= box.y_lo || box.z_hi <= box.z_lo) return hipSuccess;  // no water at all
         ty0 = box.y_lo / TY;
         ty1 = (std::min(box.y_hi, g.H) + TY - 1) / TY;
-        r.zout_lo = std::max(0, box.z_lo);
-        r.zout_hi = std::min(g.Dl, box.z_hi);
+        if (rg.zout_lo == 0 && rg.zout_hi == g.Dl) {
+            r.zout_lo = std::max(0, box.z_lo);
+            r.zout_hi = std::min(g.Dl, box.z_hi);
+        } else {
+            // a slab's launch also recomputes ghost planes; what lies two halo depths from this slab's own
+            // water cannot reach it before the next exchange (values spread one plane per sweep, through
+            // water cells only, and an exchange comes every LOOP_GHOST sweeps at the latest)
+            r.zout_lo = std::max(rg.zout_lo, box.z_lo - 2 * LOOP_GHOST);
+            r.zout_hi = std::min(rg.zout_hi, box.z_hi + 2 * LOOP_GHOST);
+        }
     }
     r.ytile0 = ty0;
     const int by = ty1 - ty0;

@@ -71,6 +71,13 @@ struct Backend {
     virtual int collect(int reset, uint32_t counts[2], uint32_t* left) = 0;
     virtual int adopt_received(uint32_t nb, uint32_t na, uint32_t fwd[2]) = 0;
     virtual int sync() = 0;
+    // a step with the engine's skipping (fluid_step_*): bricks far from the water, launches shaped to it
+    virtual int step_begin(int section_list) = 0;
+    virtual int step_end() = 0;
+    virtual int build_activity() = 0;
+    virtual int activity_layer(int which, void** ptr, uint64_t* bytes) = 0;
+    virtual int step_status(uint32_t words[8]) = 0;
+    virtual int set_box(int valid, uint32_t own, uint32_t y0, uint32_t y1, uint32_t x0, uint32_t x1) = 0;
     virtual hipStream_t stream() { return nullptr; }
     virtual bool on_device() const { return false; }
 };
@@ -164,6 +171,16 @@ struct EngineBackend : Backend {
         return chk(fluid_particles_adopt_received(c, nb, na, fwd));
     }
     int sync() override { return chk(fluid_sync(c)); }
+    int step_begin(int l) override { return chk(fluid_step_begin(c, l)); }
+    int step_end() override { return chk(fluid_step_end(c)); }
+    int build_activity() override { return chk(fluid_step_build_activity(c)); }
+    int activity_layer(int which, void** ptr, uint64_t* bytes) override {
+        return chk(fluid_activity_layer_ptr(c, which, ptr, bytes));
+    }
+    int step_status(uint32_t words[8]) override { return chk(fluid_step_status(c, words)); }
+    int set_box(int valid, uint32_t own, uint32_t y0, uint32_t y1, uint32_t x0, uint32_t x1) override {
+        return chk(fluid_step_set_box(c, valid, own, y0, y1, x0, x1));
+    }
     hipStream_t stream() override { return s; }
     bool on_device() const override { return true; }
 };
@@ -211,6 +228,16 @@ struct CallbackBackend : Backend {
         return CB(adopt_received, nb, na, fwd);
     }
     int sync() override { return CB(sync); }
+    int step_begin(int l) override { return CB(step_begin, l); }
+    int step_end() override { return CB(step_end); }
+    int build_activity() override { return CB(build_activity); }
+    int activity_layer(int which, void** ptr, uint64_t* bytes) override {
+        return CB(activity_layer, which, ptr, bytes);
+    }
+    int step_status(uint32_t words[8]) override { return CB(step_status, words); }
+    int set_box(int valid, uint32_t own, uint32_t y0, uint32_t y1, uint32_t x0, uint32_t x1) override {
+        return CB(set_box, valid, own, y0, y1, x0, x1);
+    }
 #undef CB
 };
 
@@ -704,10 +731,46 @@ int advect(fluid_slab* s) {
         return FLUID_OK;
     };
     TRY(run());
+    // One host synchronisation per step, here: the halo-violation flag of the pass and — it has had the pass
+    // to arrive — the box of this slab's water (fluid_step_status).  One reduction tells every rank every
+    // rank's flag and box; the launches of the pressure loop then cover the union of this slab's box with its
+    // neighbours' (their water is what the ghost planes hold).
+    uint32_t w[8];
+    BE(step_status(w));
+    uint32_t flag = w[0];
+    constexpr uint32_t K = 7;  // words per rank: flag, box known, bricks, ~y_lo, y_hi, ~x_lo, x_hi
+    std::vector<uint32_t> table((size_t)K * s->world, 0u);
+    uint32_t* mine = table.data() + (size_t)K * s->rank;
+    mine[0] = flag;
+    mine[1] = w[1];
+    mine[2] = w[2];
+    mine[3] = ~w[3];  // MAX of the complements = complement of the MIN
+    mine[4] = w[4];
+    mine[5] = ~w[5];
+    mine[6] = w[6];
+    TRY(reduce_max(s, table.data(), (uint32_t)table.size()));
+    {
+        bool known = true;
+        uint32_t y0 = ~0u, y1 = 0, x0 = ~0u, x1 = 0;
+        const int peers[3] = {(int)s->rank, s->loopback ? -1 : s->lo, s->loopback ? -1 : s->hi};
+        for (int q : peers) {
+            if (q < 0) continue;
+            const uint32_t* t = table.data() + (size_t)K * q;
+            known = known && t[1] != 0;
+            if (t[2] == 0) continue;  // no water there
+            y0 = std::min(y0, ~t[3]);
+            y1 = std::max(y1, t[4]);
+            x0 = std::min(x0, ~t[5]);
+            x1 = std::max(x1, t[6]);
+        }
+        // (a loopback rehearsal takes its own box for its neighbours': same launch shapes as a real run of
+        // a scene that looks alike on both sides of the face)
+        if (y1 <= y0) y0 = y1 = x0 = x1 = 0;
+        BE(set_box(known ? 1 : 0, mine[2], y0, y1, x0, x1));
+    }
+    flag = 0;
+    for (uint32_t q = 0; q < s->world; q++) flag |= table[(size_t)K * q];
     if (!s->has_peers()) return FLUID_OK;  // a whole-grid context clamps its taps into the grid
-    uint32_t flag = 0;
-    BE(slab_status(&flag));
-    TRY(reduce_max(s, &flag, 1));
     if (!flag) return FLUID_OK;
     s->stats[FLUID_SLAB_STAT_SAMPLER_RERUNS]++;
     uint32_t reach = 0;
@@ -801,7 +864,34 @@ int run_init(fluid_slab* s) {
 }
 
 // SimulationStepSections 01a ... 14 (fluid_flow_sections.h:163-338) on this slab
-int run_step(fluid_slab* s) {
+int exchange_activity(fluid_slab* s) {
+    BE(build_activity());
+    if (!s->has_peers() || !s->tr) return FLUID_OK;
+    void* ptr[4];
+    uint64_t bytes[4];
+    for (int i = 0; i < 4; i++) BE(activity_layer(i, &ptr[i], &bytes[i]));
+    if (bytes[0] == 0) return FLUID_OK;  // this step does not skip
+    std::vector<Xfer> ops;
+    auto add = [&](int which, int peer, bool send) {
+        Xfer x{};
+        x.ptr = ptr[which];
+        x.bytes = bytes[which];
+        x.peer = peer;
+        x.flags = send ? FLUID_XFER_SEND : 0u;
+        ops.push_back(x);
+    };
+    if (s->lo >= 0) {
+        add(0, s->lo, true);
+        add(2, s->lo, false);
+    }
+    if (s->hi >= 0) {
+        add(1, s->hi, true);
+        add(3, s->hi, false);
+    }
+    return exchange_now(s, ops);
+}
+
+int run_step_sections(fluid_slab* s) {
     BE(run_section(FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES));
     BE(run_section(FLUID_SEC_01_UPDATE_DENSITIES));  // owned particles only, into owned planes
     BE(run_section(FLUID_SEC_02_UPDATE_WATER));
@@ -816,6 +906,7 @@ int run_step(fluid_slab* s) {
     }
     TRY(exchange_image(s, FLUID_IMG_VELOCITIES_1, s->sampler_halo));  // 07 samples V1 around each cell
     BE(run_section(FLUID_SEC_06_UPDATE_CELL_TYPES));  // carries one ghost plane per side along
+    TRY(exchange_activity(s));                        // which bricks hold water, also across the faces
     TRY(advect(s));                                   // 07, 08
     const bool intended = s->diffuse_mode == FLUID_DIFFUSE_INTENDED;
     if (s->grouped && s->W % 4 == 0 && !intended) {
@@ -837,6 +928,13 @@ int run_step(fluid_slab* s) {
     TRY(exchange_image(s, FLUID_IMG_VELOCITIES_1, std::min<uint32_t>(2, s->image_ghost)));
     BE(run_section(FLUID_SEC_14_PARTICLES));
     return migrate(s);
+}
+
+int run_step(fluid_slab* s) {
+    BE(step_begin(s->grouped ? 0 : 1));
+    const int rc = run_step_sections(s);
+    const int rc2 = s->from_backend(s->be->step_end());
+    return rc ? rc : rc2;
 }
 
 int fill_common(fluid_slab* s, const fluid_slab_create_info* info, const fluid_params& p) {

@@ -87,6 +87,8 @@ EXPORTED_SYMBOLS = [
     "fluid_get_geometry", "fluid_set_option", "fluid_count_nonfinite",
     "fluid_set_sampler_halo", "fluid_sampler_reach", "fluid_sampler_wide_begin",
     "fluid_sampler_wide_plane_ptr", "fluid_run_advect_wide",
+    "fluid_step_begin", "fluid_step_end", "fluid_step_build_activity", "fluid_activity_layer_ptr",
+    "fluid_step_status", "fluid_step_set_box",
 ]
 
 
@@ -188,6 +190,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_sampler_wide_begin": (C.c_int, [vp, u32, u32]),
         "fluid_sampler_wide_plane_ptr": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_run_advect_wide": (C.c_int, [vp, C.c_int]),
+        "fluid_step_begin": (C.c_int, [vp, C.c_int]),
+        "fluid_step_end": (C.c_int, [vp]),
+        "fluid_step_build_activity": (C.c_int, [vp]),
+        "fluid_activity_layer_ptr": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(u64)]),
+        "fluid_step_status": (C.c_int, [vp, C.POINTER(u32 * 8)]),
+        "fluid_step_set_box": (C.c_int, [vp, C.c_int, u32, u32, u32, u32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -92,6 +92,12 @@ _BACKEND_FIELDS = [   # order = include/fluid_slab.h: fluid_slab_backend
     ("collect", [C.c_int, _pu32, _pu32]),
     ("adopt_received", [_u32, _u32, _pu32]),
     ("sync", []),
+    ("step_begin", [C.c_int]),
+    ("step_end", []),
+    ("build_activity", []),
+    ("activity_layer", [C.c_int, _pvp, _pu64]),
+    ("step_status", [_pu32]),
+    ("set_box", [C.c_int, _u32, _u32, _u32, _u32, _u32]),
 ]
 _BACKEND_FN = {name: C.CFUNCTYPE(C.c_int, C.c_void_p, *args) for name, args in _BACKEND_FIELDS}
 
@@ -350,6 +356,27 @@ class CallbackBackend:
 
     def _sync(self):
         self.compute.sync()
+
+    # a compute object without the engine's skipping: no activity layers to exchange, box unknown
+    def _step_begin(self, section_list):
+        getattr(self.compute, "step_begin", lambda: None)()
+
+    def _step_end(self):
+        getattr(self.compute, "step_end", lambda: None)()
+
+    def _build_activity(self):
+        pass
+
+    def _activity_layer(self, which, ptr, nbytes):
+        ptr[0], nbytes[0] = None, 0
+
+    def _step_status(self, words):
+        for i in range(8):
+            words[i] = 0
+        words[0] = 1 if self.compute.halo_violation() else 0
+
+    def _set_box(self, valid, own, y0, y1, x0, x1):
+        pass
 
 
 class SlabError(RuntimeError):
