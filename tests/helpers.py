@@ -103,6 +103,22 @@ def assert_bit_equal(got: np.ndarray, exp: np.ndarray, what: str):
             f"got {got[first]!r} expected {exp[first]!r}")
 
 
+def assert_bit_equal_any_nan(got: np.ndarray, exp: np.ndarray, what: str):
+    """Bit-exact, except that a NaN matches a NaN of any sign / payload.  For inputs that hold +-inf: an
+    invalid operation (inf - inf, 0 * inf) GENERATES a NaN, and IEEE 754 leaves its bits to the implementation:
+    x86 SSE gives the negative default NaN 0xFFC00000, gfx950 the positive 0x7FC00000.  (A NaN that is merely
+    propagated, and the 0 / 0 of a walled-in pressure cell, come out identical and are compared bit for bit
+    elsewhere.)"""
+    assert got.shape == exp.shape and got.dtype == np.float32
+    gb, eb = bits(np.ascontiguousarray(got)), bits(np.ascontiguousarray(exp))
+    differ = (gb != eb) & ~(np.isnan(got) & np.isnan(exp))
+    if differ.any():
+        first = tuple(np.argwhere(differ)[0])
+        raise AssertionError(f"{what}: {int(differ.sum())} of {gb.size} elements differ (NaN vs NaN not "
+                             f"counted); first at {first}: got {got[first]!r} ({gb[first]:#x}) expected "
+                             f"{exp[first]!r} ({eb[first]:#x})")
+
+
 def assert_state_equal(eng, state: OracleState, fields=None, ctx=""):
     got = download_state(eng, state)
     for name in (fields or list(IMAGE_FIELDS) + ["particles"]):

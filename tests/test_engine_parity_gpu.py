@@ -14,8 +14,8 @@ import fluid_amd
 from fluid_amd import engine as E
 from fluid_amd import scenes
 from fluid_amd.params import CELL_AIR, CELL_SOLID, CELL_WATER, dam_break_params, default_params
-from helpers import (IMAGE_FIELDS, assert_bit_equal, assert_state_equal, download_state,
-                     make_engine, random_state, upload_state)
+from helpers import (IMAGE_FIELDS, assert_bit_equal, assert_bit_equal_any_nan, assert_state_equal,
+                     download_state, make_engine, random_state, upload_state)
 from oracle_binding import OracleState
 
 pytestmark = pytest.mark.gpu
@@ -915,6 +915,37 @@ def test_advect_tiled_sampler_and_fallback(kernel, size, dt, scale):
         st.run_section("07_advect")
         st.run_section("08_forces")
         assert_state_equal(eng, st, ctx=f"07+08 kernel {kernel} dt {dt}: ")
+
+
+@pytest.mark.parametrize("fraction", [0.0, 0.002, 0.05])
+@pytest.mark.parametrize("size", [(64, 8, 32), (128, 16, 64)])
+def test_advect_face_shortcut_and_special_values(size, fraction):
+    """On a grid whose extents are all powers of two the tiled 07 kernel takes the three face-position
+    samples of advect.comp:75 without the sampler's arithmetic — unless the planes it reads hold a value
+    for which `(1 - 0) * A + 0 * B` is not A: -0, a denormal (0.5 * A may underflow to -0), inf, NaN.  Those
+    are sprinkled over VELOCITIES_1 here (whole planes stay clean at the low fraction, so both paths run in
+    one launch); every texel must equal the oracle's bit for bit (a generated NaN matches any NaN: helpers)."""
+    st = random_state(size, seed=77, iters=2, velocity_scale=2.0)
+    rng = np.random.default_rng(5)
+    v = st.velocities_1
+    specials = np.array([-0.0, 1e-40, -3e-42, np.inf, -np.inf, np.nan, 0.0], np.float32)
+    if fraction:
+        hit = rng.uniform(0, 1, v.shape) < fraction
+        if fraction < 0.01:
+            hit[: v.shape[0] // 2] = False     # the lower half of the planes stays regular
+        v[hit] = rng.choice(specials, size=int(hit.sum()))
+    with make_engine(st) as eng, np.errstate(all="ignore"):
+        for kernel in (0, 1):   # LDS-tiled with the shortcut; taps straight from global memory
+            eng.set_option(E.OPT_ADVECT_KERNEL, kernel)
+            eng.run_section("07_advect")
+            st.run_section("07_advect")
+            assert_bit_equal_any_nan(eng.download_image(E.VELOCITIES_2), st.velocities_2,
+                                     f"07 kernel {kernel}, special fraction {fraction}")
+            eng.run_section_group("07_advect", 2)
+            st.run_section("07_advect")
+            st.run_section("08_forces")
+            assert_bit_equal_any_nan(eng.download_image(E.VELOCITIES_2), st.velocities_2,
+                                     f"07+08 kernel {kernel}, special fraction {fraction}")
 
 
 def test_checkpoint_round_trip(tmp_path):

@@ -895,8 +895,9 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
                                    c->flags(), c->quiet_or_null(), bk, qchunks);
             else
-                hipLaunchKernelGGL(k07_advect_tiled<true>, qgrid, block, 0, c->stream, T, V1, V2, g,
-                                   pk, c->flags(), c->quiet_or_null(), bk, qchunks);
+                hipLaunchKernelGGL(k07_advect_tiled<true>, dim3(qgrid.x, qgrid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
+                                   block, 0, c->stream, T, V1, V2, g, pk, c->flags(), c->quiet_or_null(), bk,
+                                   qchunks, c->quiet_in_use ? c->bricks() : (const uint8_t*)nullptr);
             break;
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
@@ -917,8 +918,9 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k07_advect<false>, grid, block, 0, c->stream, T, V1, V2, g, pk,
                                    c->flags(), (const uint8_t*)nullptr, bk, 1);
             else
-                hipLaunchKernelGGL(k07_advect_tiled<false>, grid, block, 0, c->stream, T, V1, V2, g,
-                                   pk, c->flags(), (const uint8_t*)nullptr, bk, 1);
+                hipLaunchKernelGGL(k07_advect_tiled<false>, dim3(grid.x, grid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
+                                   block, 0, c->stream, T, V1, V2, g, pk, c->flags(), (const uint8_t*)nullptr,
+                                   bk, 1, (const uint8_t*)nullptr);
             break;
         case FLUID_SEC_08_FORCES:
             hipLaunchKernelGGL(k08_forces, grid, block, 0, c->stream, T, V2, g, pk);

@@ -6,6 +6,9 @@
 #include "device_common.h"
 #include "quiet_bricks.h"
 
+// bitwise OR over the workgroup with a barrier (ROCm device library; __syncthreads_or reduces !!predicate)
+extern "C" __device__ int __ockl_wgred_or_i32(int);
+
 namespace fluid {
 
 // One axis of `texture(velocities, (pos + move) / fluid_size)` with VK_FILTER_LINEAR and
@@ -63,10 +66,12 @@ __device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0,
 }
 __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f - a) * A + a * B; }
 
-// Velocity tile in LDS (k07_advect_tiled): the cells of a workgroup plus TILE_HALO cells around them,
-// one array per component so that neighbouring lanes read neighbouring banks.  Tile cell (tx, ty, tz)
-// holds the texel at grid index (x_org + tx, y_org + ty, local plane z_org + tz); cells outside the
-// image are never addressed (taps are clamped into the image before the lookup).
+// Velocity tile in LDS (k07_advect_tiled): the 64 x 4 cells of a workgroup plus TILE_HALO cells around them
+// in x and y, over a window of TILE_D planes that slides along z with the workgroup's march (a ring: the
+// plane that enters overwrites the one that left); one array per component so that neighbouring lanes read
+// neighbouring banks.  Tile cell (tx, ty, slot) holds the texel at grid index (x_org + tx, y_org + ty, local
+// plane z): slot(z) = (z - z_lo + z_rot) mod TILE_D for the planes z_lo .. z_lo + TILE_D - 1 of the window;
+// cells outside the image are never addressed (taps are clamped into the image before the lookup).
 #define FLUID_LDS_F __attribute__((address_space(3)))
 constexpr int TILE_HALO = 2;
 constexpr int TILE_W = 64 + 2 * TILE_HALO, TILE_H = 4 + 2 * TILE_HALO, TILE_D = 1 + 2 * TILE_HALO;
@@ -77,7 +82,14 @@ struct NoTile {
 struct VelTile {
     static constexpr bool enabled = true;
     const FLUID_LDS_F float* comp[3];
-    int x_org, y_org, z_org;
+    int x_org, y_org, z_lo, z_rot;
+    // ring slot of local plane z, or -1 when the plane is not in the window
+    __device__ __forceinline__ int slot(int z) const {
+        const int d = z - z_lo;
+        if ((unsigned)d >= (unsigned)TILE_D) return -1;
+        const int sl = d + z_rot;
+        return sl >= TILE_D ? sl - TILE_D : sl;
+    }
 };
 
 // Component COMP of the trilinear sample at world position (px,py,pz).  `v` addresses owned plane 0
@@ -111,10 +123,10 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
     bool from_tile = false;
     if constexpr (Tile::enabled) {
         const int tx0 = x0 - tile.x_org, tx1 = x1 - tile.x_org, ty0 = y0 - tile.y_org,
-                  ty1 = y1 - tile.y_org, tz0 = z0 - tile.z_org, tz1 = z1 - tile.z_org;
+                  ty1 = y1 - tile.y_org, tz0 = tile.slot(z0), tz1 = tile.slot(z1);
         from_tile = (unsigned)tx0 < (unsigned)TILE_W && (unsigned)tx1 < (unsigned)TILE_W &&
-                    (unsigned)ty0 < (unsigned)TILE_H && (unsigned)ty1 < (unsigned)TILE_H &&
-                    (unsigned)tz0 < (unsigned)TILE_D && (unsigned)tz1 < (unsigned)TILE_D;
+                    (unsigned)ty0 < (unsigned)TILE_H && (unsigned)ty1 < (unsigned)TILE_H && tz0 >= 0 &&
+                    tz1 >= 0;
         if (from_tile) {
             const FLUID_LDS_F float* t = tile.comp[COMP];
             const int r00 = TILE_W * (ty0 + TILE_H * tz0), r10 = TILE_W * (ty1 + TILE_H * tz0);
@@ -126,16 +138,61 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
         }
     }
     if (!from_tile) {
-        const float* __restrict__ f = reinterpret_cast<const float*>(v) + COMP;
-        c000 = f[4 * cidx(g, x0, y0, z0)]; c100 = f[4 * cidx(g, x1, y0, z0)];
-        c010 = f[4 * cidx(g, x0, y1, z0)]; c110 = f[4 * cidx(g, x1, y1, z0)];
-        c001 = f[4 * cidx(g, x0, y0, z1)]; c101 = f[4 * cidx(g, x1, y0, z1)];
-        c011 = f[4 * cidx(g, x0, y1, z1)]; c111 = f[4 * cidx(g, x1, y1, z1)];
+        // one 64-bit texel address (the corner x0, y0, z0), the other seven taps at small 32-bit offsets
+        // from it: the steps along the axes are 0 or 1 texel (0 where the tap is clamped at an edge)
+        const float* __restrict__ f = reinterpret_cast<const float*>(v + cidx(g, x0, y0, z0)) + COMP;
+        const int dx = 4 * (x1 - x0), dy = 4 * (y1 - y0) * g.W, dz = 4 * (z1 - z0) * (int)g.plane;
+        c000 = f[0];       c100 = f[dx];
+        c010 = f[dy];      c110 = f[dx + dy];
+        c001 = f[dz];      c101 = f[dx + dz];
+        c011 = f[dy + dz]; c111 = f[dx + dy + dz];
     }
     const float c00 = lerp1(c000, c100, ax), c10 = lerp1(c010, c110, ax);
     const float c01 = lerp1(c001, c101, ax), c11 = lerp1(c011, c111, ax);
     const float c0 = lerp1(c00, c10, ay), c1 = lerp1(c01, c11, ay);
     return lerp1(c0, c1, az);
+}
+
+// The three samples advect.comp:75 takes at a face position, without the sampler's arithmetic.  At the
+// centre of the -COMP face of cell (x, y, z) the texture coordinates of the three components fall on texel
+// centres or half way between two of them: component COMP has filter weight a = 0 on every axis, the other
+// two have a = 1/2 along their own axis (texels p, p+1) and along COMP (texels p-1, p) and a = 0 on the third.
+// That is exact only where coord / n * n returns coord — true for every coordinate when n is a power of two
+// (axis_taps' pow2 path; all BASELINE grids), which the caller checks — and a lerp with a = 0,
+// (1 - 0) * A + 0 * B, may be replaced by A only if A is not -0 and B is finite: the workgroup scans its
+// tile for -0, denormals (0.5 * A may underflow to -0), inf and NaN while staging it and takes the general
+// path if it finds one.  The a = 1/2 lerps are evaluated as written, (1 - 0.5f) * A + 0.5f * B.
+__device__ __forceinline__ bool sampler_special_value(float v) {
+    const uint32_t b = __float_as_uint(v), e = b & 0x7F800000u;
+    return e == 0x7F800000u || (e == 0u && b != 0u);
+}
+template <int COMP>
+__device__ __forceinline__ float3 face_velocity(const VelTile& tile, const GridK& g, int x, int y, int lz,
+                                                int gz) {
+    // clamped neighbour indices (CLAMP_TO_EDGE), as tile coordinates
+    const int tx = x - tile.x_org, ty = y - tile.y_org, tz = tile.slot(lz);
+    const int txm = tx - (x > 0), txp = tx + (x < g.W - 1);
+    const int tym = ty - (y > 0), typ = ty + (y < g.H - 1);
+    const int tzm = tile.slot(lz - (gz > 0)), tzp = tile.slot(lz + (gz < g.Dg - 1));
+    auto at = [&](int comp, int ax, int ay, int az) {
+        return tile.comp[comp][ax + TILE_W * (ay + TILE_H * az)];
+    };
+    auto half = [](float A, float B) { return (1.0f - 0.5f) * A + 0.5f * B; };  // lerp1(A, B, 0.5f)
+    float3 v;
+    if (COMP == 0) {
+        v.x = at(0, tx, ty, tz);
+        v.y = half(half(at(1, txm, ty, tz), at(1, tx, ty, tz)), half(at(1, txm, typ, tz), at(1, tx, typ, tz)));
+        v.z = half(half(at(2, txm, ty, tz), at(2, tx, ty, tz)), half(at(2, txm, ty, tzp), at(2, tx, ty, tzp)));
+    } else if (COMP == 1) {
+        v.x = half(half(at(0, tx, tym, tz), at(0, txp, tym, tz)), half(at(0, tx, ty, tz), at(0, txp, ty, tz)));
+        v.y = at(1, tx, ty, tz);
+        v.z = half(half(at(2, tx, tym, tz), at(2, tx, ty, tz)), half(at(2, tx, tym, tzp), at(2, tx, ty, tzp)));
+    } else {
+        v.x = half(half(at(0, tx, ty, tzm), at(0, txp, ty, tzm)), half(at(0, tx, ty, tz), at(0, txp, ty, tz)));
+        v.y = half(half(at(1, tx, ty, tzm), at(1, tx, typ, tzm)), half(at(1, tx, ty, tz), at(1, tx, typ, tz)));
+        v.z = at(2, tx, ty, tz);
+    }
+    return v;
 }
 
 template <int COMP, typename Tile = NoTile>
@@ -145,7 +202,7 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
                                                   int lz, int gz,
                                                   bool cur_water, float keep,
                                                   uint32_t* __restrict__ violation,
-                                                  const Tile& tile = Tile()) {
+                                                  const Tile& tile = Tile(), bool fast_faces = false) {
     const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
     // advect.comp:65-68: move[c] = -1; cellAt(pos - move) is the cell at pos + e_c
     const uint32_t nt =
@@ -154,9 +211,22 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
         const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
         const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
         const float qz = (float)gz + (COMP == 2 ? 0.0f : 0.5f);
-        const float vx = sample_comp<0, Tile>(v1, g, axes, qx, qy, qz, violation, tile);  // :75
-        const float vy = sample_comp<1, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
-        const float vz = sample_comp<2, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+        float vx = 0.f, vy = 0.f, vz = 0.f;  // :75
+        bool done = false;
+        if constexpr (Tile::enabled) {
+            if (fast_faces) {  // workgroup-uniform
+                const float3 v = face_velocity<COMP>(tile, g, x, y, lz, gz);
+                vx = v.x;
+                vy = v.y;
+                vz = v.z;
+                done = true;
+            }
+        }
+        if (!done) {
+            vx = sample_comp<0, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+            vy = sample_comp<1, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+            vz = sample_comp<2, Tile>(v1, g, axes, qx, qy, qz, violation, tile);
+        }
         return sample_comp<COMP, Tile>(v1, g, axes, qx - vx * p.dt, qy - vy * p.dt, qz - vz * p.dt,
                                        violation, tile);  // :77
     }
@@ -207,24 +277,63 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
     FLUID_END_FOR_CELLS
 }
 
-// 07_advect (+ 08_forces) with the velocity sampler tiled into LDS.  A workgroup of 64 x 4 cells of one
-// plane first votes whether any of its cells is advected at all (cell or +x/+y/+z neighbour WATER,
-// advect.comp:65-68); if so it stages the velocities of its cells and TILE_HALO cells around them in LDS
-// (coalesced float4 loads along x, stored per component), and the twelve trilinear samples per cell
-// (three at the face position for the back-trace, one at the back-traced position, per component) read
-// their 8 taps from the tile: the face-position samples always lie inside it, a back-trace that leaves
-// it (more than TILE_HALO cells away) falls back to global loads.  Same arithmetic as k07_advect.
+// 07_advect (+ 08_forces) with the velocity sampler tiled into LDS.  A workgroup of 64 x 4 threads marches
+// over ZM planes (one brick layer) of its 64 x 4-cell column with a window of five planes of VELOCITIES_1
+// (its cells + TILE_HALO cells around them) in LDS: per plane step it stages the ONE plane that enters the
+// window (coalesced float4 loads along x, stored per component; 2.1 texels per thread instead of the 10.6 of
+// a tile staged afresh for every plane), and the twelve trilinear samples per advected cell (three at the
+// face position for the back-trace, one at the back-traced position, per component) read their 8 taps from
+// the window: the face-position samples always lie inside it — and cost no sampler arithmetic where
+// face_velocity applies —, a back-trace that leaves it (more than TILE_HALO cells away) falls back to global
+// loads.  Planes in which no cell of the column is advected (cell or +x/+y/+z neighbour WATER,
+// advect.comp:65-68) only copy.  Same arithmetic as k07_advect.
+constexpr int K07_ZM = 16;  // = BRICK_Z: a workgroup stays inside one brick (quiet_bricks.h)
 template <bool FORCES>
 __global__ void __launch_bounds__(256)
 k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                  float4* __restrict__ v2, GridK g, ParamsK p, uint32_t* __restrict__ violation,
-                 const uint8_t* __restrict__ quiet, BrickK bk, int xchunks) {
-    FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)  // quiet_bricks.h
+                 const uint8_t* __restrict__ quiet, BrickK bk, int xchunks,
+                 const uint8_t* __restrict__ active) {
+    static_assert(K07_ZM == BRICK_Z && TILE_D == 2 * TILE_HALO + 1, "march = one brick layer");
+    if (quiet) {  // blockIdx.z counts brick layers here
+        const int qb = brick_index(bk, (int)(blockIdx.x * 64u * (unsigned)xchunks) / BRICK_X,
+                                   (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z);
+        if ((uint32_t)quiet[qb] >= QUIET_MIN_STREAK) return;
+    }
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int zb = (int)blockIdx.z * K07_ZM, ze = min(zb + K07_ZM, g.Dl);
+    // `active` (optional): the activity bricks of the CELL_TYPES this pass reads.  A cell is advected if it or
+    // its +x / +y / +z neighbour is water (advect.comp:65-68) and takes a force if it or the cell below it is
+    // water (forces.comp:39-49): with no water in this workgroup's brick nor in the bricks beyond its +x, +y,
+    // +z and -y faces the pass is a copy with w = 0.  A brick layer of a neighbouring slab counts as wet.
+    if (active && xchunks == BRICK_X / 64) {
+        const int bx = (int)blockIdx.x, by = (int)(blockIdx.y * 4u) / BRICK_Y, bz = (int)blockIdx.z;
+        uint32_t any = active[brick_index(bk, bx, by, bz)];
+        if (bx + 1 < bk.nbx) any |= active[brick_index(bk, bx + 1, by, bz)];
+        if (by + 1 < bk.nby) any |= active[brick_index(bk, bx, by + 1, bz)];
+        if (by > 0) any |= active[brick_index(bk, bx, by - 1, bz)];
+        if (bz + 1 < bk.nbz)
+            any |= active[brick_index(bk, bx, by, bz + 1)];
+        else
+            any |= g.z0 + g.Dl < g.Dg ? 1u : 0u;
+        if (any == 0) {
+            if (y < g.H)
+                for (int xc = 0; xc < xchunks; xc++) {
+                    const int x = ((int)blockIdx.x * xchunks + xc) * 64 + (int)threadIdx.x;
+                    if (x >= g.W) break;
+                    for (int lz = zb; lz < ze; lz++) {
+                        const int64_t id = cidx(g, x, y, lz);
+                        float4 o = v1[id];
+                        o.w = 0.0f;
+                        v2[id] = o;
+                    }
+                }
+            return;
+        }
+    }
     __shared__ float tile_mem[3][TILE_CELLS];
     const Axes axes = make_axes(g);
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int lz = blockIdx.z;
-    const int gz = g.z0 + lz;
+    const bool pow2_grid = axes.x.pow2 && axes.y.pow2 && axes.z.pow2;  // coord / n * n == coord everywhere
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // planes of the image that exist for this context (ghost planes of a slab; the grid itself otherwise)
     const int zlo = max(-g.sg_lo, -g.z0), zhi = min(g.Dl + g.sg_hi - 1, g.Dg - 1 - g.z0);
@@ -233,52 +342,89 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
         if (xb >= g.W) break;                                  // uniform
         const int x = xb + (int)threadIdx.x;
         const bool valid = x < g.W && y < g.H;
-        int64_t id = 0;
-        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool cur_water = false, adv = false;
-        if (valid) {
-            id = cidx(g, x, y, lz);
-            cur = v1[id];                                   // :87
-            cur_water = (uint32_t)t[id] == p.t_water;       // :93
-            adv = cur_water || type_at(t, g, x + 1, y, lz) == p.t_water ||
-                  type_at(t, g, x, y + 1, lz) == p.t_water ||
-                  (uint32_t)t[cidx(g, x, y, lz + 1)] == p.t_water;
-        }
-        const bool any_adv = __syncthreads_or(adv ? 1 : 0) != 0;  // also fences the previous chunk's reads
         VelTile tile;
         tile.comp[0] = (const FLUID_LDS_F float*)tile_mem[0];
         tile.comp[1] = (const FLUID_LDS_F float*)tile_mem[1];
         tile.comp[2] = (const FLUID_LDS_F float*)tile_mem[2];
         tile.x_org = xb - TILE_HALO;
         tile.y_org = (int)blockIdx.y * 4 - TILE_HALO;
-        tile.z_org = lz - TILE_HALO;
-        if (any_adv) {
-            for (int i = tid; i < TILE_CELLS; i += 256) {
-                const int tx = i % TILE_W, ty = (i / TILE_W) % TILE_H, tz = i / (TILE_W * TILE_H);
-                const int cx = tile.x_org + tx, cy = tile.y_org + ty, cz = tile.z_org + tz;
-                if ((unsigned)cx < (unsigned)g.W && (unsigned)cy < (unsigned)g.H && cz >= zlo && cz <= zhi) {
-                    const float4 q = v1[cidx(g, cx, cy, cz)];
-                    tile_mem[0][i] = q.x;
-                    tile_mem[1][i] = q.y;
-                    tile_mem[2][i] = q.z;
+        // stage plane cz of the window into ring slot `sl`; returns whether it holds a value the face
+        // shortcut cannot take (per thread; the caller votes)
+        auto stage = [&](int cz, int sl) -> bool {
+            bool special = false;
+            if (cz >= zlo && cz <= zhi)
+                for (int i = tid; i < TILE_W * TILE_H; i += 256) {
+                    const int tx = i % TILE_W, ty = i / TILE_W;
+                    const int cx = tile.x_org + tx, cy = tile.y_org + ty;
+                    if ((unsigned)cx < (unsigned)g.W && (unsigned)cy < (unsigned)g.H) {
+                        const float4 q = v1[cidx(g, cx, cy, cz)];
+                        const int o = i + TILE_W * TILE_H * sl;
+                        tile_mem[0][o] = q.x;
+                        tile_mem[1][o] = q.y;
+                        tile_mem[2][o] = q.z;
+                        special = special || sampler_special_value(q.x) || sampler_special_value(q.y) ||
+                                  sampler_special_value(q.z);
+                    }
+                }
+            return special;
+        };
+        // The window is staged lazily: planes [have_lo, have_hi) are in the ring, plane z in slot
+        // (z - zb + TILE_HALO) mod TILE_D.  A plane whose cells are not advected costs its vote only; a run of
+        // advected planes stages one new plane per step.  (Workgroup-uniform bookkeeping.)
+        auto slot_of = [&](int z) { return (z - zb + TILE_HALO) % TILE_D; };
+        int have_lo = 0, have_hi = 0;
+        uint32_t bad = 0;  // bit k: the plane in ring slot k holds a special value
+        for (int lz = zb; lz < ze; lz++) {
+            const int gz = g.z0 + lz;
+            int64_t id = 0;
+            float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool cur_water = false, adv = false;
+            if (valid) {
+                id = cidx(g, x, y, lz);
+                cur = v1[id];                                   // :87
+                cur_water = (uint32_t)t[id] == p.t_water;       // :93
+                adv = cur_water || type_at(t, g, x + 1, y, lz) == p.t_water ||
+                      type_at(t, g, x, y + 1, lz) == p.t_water ||
+                      (uint32_t)t[cidx(g, x, y, lz + 1)] == p.t_water;
+            }
+            // the vote is also the barrier behind the previous plane's reads of the window
+            const bool any_adv = __ockl_wgred_or_i32(adv ? 1 : 0) != 0;
+            float4 o = cur;
+            if (any_adv) {
+                const int need_lo = lz - TILE_HALO, need_hi = lz + TILE_HALO + 1;
+                int from = need_lo;
+                if (have_lo <= need_lo && have_hi > need_lo) from = min(have_hi, need_hi);  // extend the run
+                uint32_t sp_bits = 0, staged = 0;
+                for (int z = from; z < need_hi; z++) {
+                    const int sl = slot_of(z);
+                    staged |= 1u << sl;
+                    if (stage(z, sl)) sp_bits |= 1u << sl;
+                }
+                have_lo = need_lo;
+                have_hi = need_hi;
+                // bitwise OR over the workgroup (and the barrier in front of the window's readers)
+                bad = (bad & ~staged) | (uint32_t)__ockl_wgred_or_i32((int)sp_bits);
+                tile.z_lo = need_lo;
+                tile.z_rot = slot_of(need_lo);
+                // the face samples touch the planes lz-1, lz, lz+1
+                const uint32_t faces = (1u << slot_of(lz - 1)) | (1u << slot_of(lz)) | (1u << slot_of(lz + 1));
+                const bool fast_faces = pow2_grid && (bad & faces) == 0u;
+                if (adv) {
+                    o.x = advect_component<0, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.x,
+                                                       violation, tile, fast_faces);
+                    o.y = advect_component<1, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y,
+                                                       violation, tile, fast_faces);
+                    o.z = advect_component<2, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z,
+                                                       violation, tile, fast_faces);
                 }
             }
-            __syncthreads();
-        }
-        if (valid) {
-            float4 o = cur;
-            if (adv) {
-                o.x = advect_component<0, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.x,
-                                                   violation, tile);
-                o.y = advect_component<1, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y,
-                                                   violation, tile);
-                o.z = advect_component<2, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z,
-                                                   violation, tile);
+            if (valid) {
+                o.w = 0.0f;
+                if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water);
+                v2[id] = o;  // :96
             }
-            o.w = 0.0f;
-            if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water);
-            v2[id] = o;  // :96
         }
+        __syncthreads();  // the last plane's reads are done before the next chunk stages
     }
 }
 

@@ -195,7 +195,19 @@ template <int NT, bool WIN>
 static hipError_t launch_rg(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g, float p_oob,
                             const FusedRange& rg, const ActiveBox& box, int part, int part_lo, int part_hi) {
-    switch (fused_rows_per_wave(NT)) {
+    int rows_per_wave = fused_rows_per_wave(NT);
+    if (rows_per_wave > 1 && box.valid && getenv("FLUID_FUSED_RG") == nullptr) {
+        // A launch shaped to a small box of water has few workgroups: 16 thin wavefronts on many CUs finish
+        // sooner than 8 fat ones on few (512^3 dam break, x-window launches: 33.7 us per two-sweep launch with
+        // RG = 1, 37.2 with RG = 3).  Estimate the workgroups of the fat shape; below two per CU, go thin.
+        const int rows = std::max(0, std::min(box.y_hi, g.H) - box.y_lo);
+        const int planes = (rg.zout_lo == 0 && rg.zout_hi == g.Dl) ? std::max(0, box.z_hi - box.z_lo)
+                                                                   : rg.zout_hi - rg.zout_lo;
+        const int ty = (8 / NT) * rows_per_wave - 2;
+        const int tiles = (rows + ty - 1) / std::max(ty, 1), chunks = (planes + 15) / 16;
+        if (tiles * chunks < 2 * cu_count()) rows_per_wave = 1;
+    }
+    switch (rows_per_wave) {
         case 1:
             return launch_nt<NT, WIN, 1>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
                                          part_lo, part_hi);
