@@ -1668,9 +1668,38 @@ int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
         // (13_fix_divergence reads PRESSURES_2)
         if (c->is_slab) return slab_unsupported(c, "the red-black SOR solver");
         c->pressure_dispatch_index = 0;
-        for (uint32_t k = 0; k < iterations; k++) {
-            int rc = timed_section(c, FLUID_SEC_12_SOLVE_PRESSURE);
+        if (fast_loop_possible(c) && fuse_enabled(c) && iterations > 0) {
+            // On the working buffers, both colours of an iteration in ONE pass over HBM: the z march forms
+            // the even cells' new values a plane ahead of the odd cells' (kernels_pressure_fused.h, SOR) —
+            // the traffic of two Jacobi sweeps per iteration instead of two whole read-modify-write passes.
+            SectionTimer tm{c};
+            int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
             if (rc) return rc;
+            rc = loop_begin(c);
+            if (rc == FLUID_OK && iterations >= 16 && c->opt[FLUID_OPT_LAUNCH_BOX] == 0) rc = refresh_box(c);
+            for (uint32_t k = 0; k < iterations && rc == FLUID_OK; k++) {
+                const int cur = c->loop_cur, dst = other_buffer(cur, cur);
+                rc = ensure_background(c, dst);
+                if (rc) break;
+                hipError_t e = k12_launch_canon2_sor(c->stream, c->mask0(), c->rhs0(), c->work0(cur),
+                                                     c->work0(dst), c->bricks(), c->g, oob_value(c), c->box,
+                                                     c->sor_omega);
+                if (e == hipSuccess) e = hipGetLastError();
+                if (e != hipSuccess) rc = c->fail(FLUID_ERR_HIP, "SOR launch: %s", hipGetErrorString(e));
+                c->loop_cur = dst;
+            }
+            if (rc == FLUID_OK) rc = export_pressures(c, c->loop_cur, -1);  // -> the water cells of PRESSURES_1
+            c->loop_open = false;
+            c->pressure_dispatch_index = iterations;
+            int rc2 = tm.end();
+            if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && iterations > 1)
+                c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += iterations - 1;
+            if (rc || rc2) return rc ? rc : rc2;
+        } else {
+            for (uint32_t k = 0; k < iterations; k++) {
+                int rc = timed_section(c, FLUID_SEC_12_SOLVE_PRESSURE);
+                if (rc) return rc;
+            }
         }
         HIP_TRY(c, hipMemcpyAsync(c->plane0<float>(FLUID_IMG_PRESSURES_2),
                                   c->plane0<float>(FLUID_IMG_PRESSURES_1), c->owned_cells() * 4,

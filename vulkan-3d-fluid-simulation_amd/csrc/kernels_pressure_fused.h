@@ -206,6 +206,7 @@ struct FusedRow {
     float4 j[4], s[4], b[4];
     uint32_t m[4];
     float padv[4];
+    int y;                    // the row (SOR kernels: its parity)
     unsigned boff, boff_pad;  // in-plane byte offsets of this lane's cells / of its pad column in this row
     bool row_in, pad_in;      // those cells exist
     bool is_out_row;          // ... and the row is one the workgroup writes
@@ -235,6 +236,8 @@ struct FusedCtx {
     bool halo_lo, halo_hi;  // wave-uniform: this group holds row 0 / row R-1 of the workgroup, which only
                             // form iterate j+1 and whose outer y neighbour comes from global memory
     bool wave_clean;        // every cell of this wavefront (and of its outer row) lies inside the grid
+    float omega;            // SOR kernels: the relaxation factor; gz0 = global z of local plane 0
+    int gz0;
 
     __device__ __forceinline__ FLUID_LDS float* row_ptr(int buf, int arr, int row) const {
         return lds + ((buf * 2 + arr) * G::R + row) * G::RW + FUSED_PAD;
@@ -264,16 +267,31 @@ struct FusedCtx {
     }
 };
 
-// the four cells of a lane: numerators from the six neighbours, quotients, water cells take them
+// the four cells of a lane: numerators from the six neighbours, quotients, water cells take them.
+// SOR (the opt-in red-black solver, fluid_set_pressure_solver): the quotient is the Gauss-Seidel value gs and
+// only the cells of the stage's colour move, c + omega * (gs - c) (oracle_12_sor_iteration's operations);
+// a lane's cells 0, 2 have one colour and 1, 3 the other: `odd` = the stage's colour sits on cells 1, 3.
+template <bool SOR>
 __device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, float4 yp, float4 zp,
                                              float4 ym, float4 zm, float left, float right,
-                                             const DivPairs& d) {
+                                             const DivPairs& d, float omega = 0.f, bool odd = false) {
     float4 n;
     n.x = canon_num(b.x, c.y, yp.x, zp.x, left, ym.x, zm.x);
     n.y = canon_num(b.y, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
     n.z = canon_num(b.z, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
     n.w = canon_num(b.w, right, yp.w, zp.w, c.z, ym.w, zm.w);
     float4 o = canon_div4(n, m, d);
+    if (SOR) {
+        o.x = c.x + omega * (o.x - c.x);
+        o.y = c.y + omega * (o.y - c.y);
+        o.z = c.z + omega * (o.z - c.z);
+        o.w = c.w + omega * (o.w - c.w);
+        o.x = (mask_is_water(m, 0) && !odd) ? o.x : c.x;
+        o.y = (mask_is_water(m, 1) && odd) ? o.y : c.y;
+        o.z = (mask_is_water(m, 2) && !odd) ? o.z : c.z;
+        o.w = (mask_is_water(m, 3) && odd) ? o.w : c.w;
+        return o;
+    }
     o.x = mask_is_water(m, 0) ? o.x : c.x;  // non-water (and out-of-grid) cells keep their constant
     o.y = mask_is_water(m, 1) ? o.y : c.y;
     o.z = mask_is_water(m, 2) ? o.z : c.z;
@@ -291,7 +309,7 @@ __device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, flo
 // Vector-memory operations retire in issue order and the compiler's s_waitcnt counts only what is issued
 // on every path, so the stores carry all their conditions in the EXEC mask (no branch around them): the
 // wait for a step's loads then never includes the stores issued after them.
-template <int NT, int RG, int I, bool WIN, bool KEEP>
+template <int NT, int RG, int I, bool WIN, bool KEEP, bool SOR>
 __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (&row)[RG], float4 (&h)[2],
                                            int zc FLUID_TRACE_ARG) {
     constexpr int buf = I & 1;
@@ -369,8 +387,9 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
             const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].j[JC] : jext_hi;
             const float left = from_lane_below(jc.w, je[i], c.lane);
             const float right = from_lane_above(jc.x, je[i], c.lane);
-            row[i].s[SC] = canon_lane(row[i].b[BC], m_c[i], jc, yp, row[i].j[JN], ym, row[i].j[JM], left,
-                                      right, d1[i]);
+            // SOR: stage 1 moves the cells with (x + y + z) even; x of a lane's cell 0 is a multiple of 4
+            row[i].s[SC] = canon_lane<SOR>(row[i].b[BC], m_c[i], jc, yp, row[i].j[JN], ym, row[i].j[JM], left,
+                                           right, d1[i], c.omega, ((row[i].y + c.gz0 + zc) & 1) != 0);
         }
     }
 #ifdef FLUID_FUSED_TRACE
@@ -404,8 +423,8 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
             const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].s[SM] : sext_hi;
             const float left = from_lane_below(sm.w, se[i], c.lane);
             const float right = from_lane_above(sm.x, se[i], c.lane);
-            o[i] = canon_lane(row[i].b[BM], row[i].m[BM], sm, yp, row[i].s[SC], ym, row[i].s[SMM], left,
-                              right, d2[i]);
+            o[i] = canon_lane<SOR>(row[i].b[BM], row[i].m[BM], sm, yp, row[i].s[SC], ym, row[i].s[SMM], left,
+                                   right, d2[i], c.omega, ((row[i].y + c.gz0 + zo) & 1) == 0);  // stage 2: odd cells
         }
     }
     // stores: every condition is in the lane predicate (see above); a lane stores only if one of its
@@ -446,12 +465,12 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
     FT(4);  // barrier
 }
 
-template <int NT, bool WIN, int RG, bool KEEP>
+template <int NT, bool WIN, int RG, bool KEEP, bool SOR>
 __global__ void __launch_bounds__(fused_waves(RG) * 64)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
            const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pmid,
            const uint8_t* __restrict__ active, BrickK bk, GridK g, float p_air, int zchunk,
-           FusedRange rg) {
+           FusedRange rg, float omega) {
     using G = FusedGeom<NT, RG>;
     constexpr int R = G::R, TY = G::TY, RW = G::RW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -470,6 +489,8 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.mlo = rg.mlo;
     c.mhi = rg.mhi;
     c.p_oob = p_air;
+    c.omega = omega;
+    c.gz0 = g.z0;
     c.lane = threadIdx.x & 63;
     // readfirstlane: tells hipcc the wave index (hence rows, tile and edge role) is wave-uniform, so it
     // lives in SGPRs and role tests become scalar branches instead of exec masking
@@ -523,6 +544,7 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
 #pragma unroll
     for (int i = 0; i < RG; i++) {
         const int y = y0 - 1 + c.rr0 + i;  // this row
+        row[i].y = y;
         const bool yin = (unsigned)y < (unsigned)g.H;
         row[i].row_in = xin && yin;        // this lane's cells exist
         row[i].is_out_row = c.rr0 + i >= 1 && c.rr0 + i <= R - 2 && row[i].row_in;
@@ -611,13 +633,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step<NT, RG, 0, WIN, KEEP>(c, row, h, zc FLUID_TRACE_PASS);
+        fused_step<NT, RG, 0, WIN, KEEP, SOR>(c, row, h, zc FLUID_TRACE_PASS);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step<NT, RG, 1, WIN, KEEP>(c, row, h, zc + 1 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 1, WIN, KEEP, SOR>(c, row, h, zc + 1 FLUID_TRACE_PASS);
         if (k + 2 >= steps) break;
-        fused_step<NT, RG, 2, WIN, KEEP>(c, row, h, zc + 2 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 2, WIN, KEEP, SOR>(c, row, h, zc + 2 FLUID_TRACE_PASS);
         if (k + 3 >= steps) break;
-        fused_step<NT, RG, 3, WIN, KEEP>(c, row, h, zc + 3 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 3, WIN, KEEP, SOR>(c, row, h, zc + 3 FLUID_TRACE_PASS);
     }
 #ifdef FLUID_FUSED_TRACE
     {

@@ -78,6 +78,10 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
 // the output planes [part_lo, part_hi) (clipped to the pass's output range), FUSED_EDGES the rest
 enum { FUSED_WHOLE = 0, FUSED_EDGES = 1, FUSED_INTERIOR = 2 };
 bool k12_canon2_supports(const GridK& g);
+// one red-black SOR iteration (colour 0 then colour 1) in one pass over HBM: work[src] -> work[dst]
+hipError_t k12_launch_canon2_sor(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                                 float* pout, const uint8_t* bricks, const GridK& g, float p_oob,
+                                 const ActiveBox& box, float omega);
 struct FusedRange;
 // the same over an x window of nt_window (1 or 2) 256-cell columns starting at rg.xwin0
 hipError_t k12_launch_canon2_win(hipStream_t s, int nt_window, const uint8_t* mask, const float* rhs,

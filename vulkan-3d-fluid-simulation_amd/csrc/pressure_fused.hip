@@ -46,6 +46,40 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
 
 }  // namespace fluid
 
+namespace fluid {
+
+// One red-black SOR iteration (both colours) in one pass: work[src] -> work[dst].  Whole-grid contexts.
+hipError_t k12_launch_canon2_sor(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                                 float* pout, const uint8_t* bricks, const GridK& g, float p_oob,
+                                 const ActiveBox& box, float omega) {
+    FusedRange rg;
+    rg.jlo = 0;
+    rg.jhi = g.Dl;
+    rg.mlo = 0;
+    rg.mhi = g.Dl;
+    rg.zout_lo = 0;
+    rg.zout_hi = g.Dl;
+    rg.ytile0 = 0;
+    rg.hole_lo = rg.hole_hi = rg.zout_hi;
+    rg.nz_lo = 0;
+    rg.xwin0 = 0;
+    rg.xcd_rows = rg.xcd_nz = 0;
+    const int nt = (g.W + 255) / 256;
+    // the instantiations the Jacobi loop defaults to for full rows (pressure_fused_launch.h)
+    if (nt == 1)
+        return launch_keep<1, false, 3, false, true>(s, mask, rhs, pin, pout, nullptr, bricks, g, p_oob, rg, box,
+                                                     FUSED_WHOLE, 0, 0, omega);
+    if (nt == 2)
+        return launch_keep<2, false, 2, false, true>(s, mask, rhs, pin, pout, nullptr, bricks, g, p_oob, rg, box,
+                                                     FUSED_WHOLE, 0, 0, omega);
+    if (nt <= 4)
+        return launch_keep<4, false, 3, false, true>(s, mask, rhs, pin, pout, nullptr, bricks, g, p_oob, rg, box,
+                                                     FUSED_WHOLE, 0, 0, omega);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fluid
+
 #ifdef FLUID_FUSED_TRACE
 // dev build: copy the phase sums of the last launch out (tools/fused_trace.py)
 extern "C" int fluid_dev_fused_trace(unsigned long long* out, int words) {

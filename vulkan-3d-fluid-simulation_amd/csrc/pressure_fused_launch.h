@@ -84,11 +84,11 @@ static inline int fused_rows_per_wave(int nt) {
     return nt == 2 ? 2 : 3;
 }
 
-template <int NT, bool WIN, int RG, bool KEEP>
+template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false>
 static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                             float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
-                            int part_lo, int part_hi) {
+                            int part_lo, int part_hi, float omega = 0.f) {
     // the dynamic-LDS limit is an attribute of the function on a device: once per instantiation and
     // device (a process may hold contexts on several)
     using G = FusedGeom<NT, RG>;
@@ -97,7 +97,7 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN, RG, KEEP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN, RG, KEEP, SOR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
@@ -173,8 +173,8 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
     bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
-    hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout, pmid,
-                       bricks, bk, g, p_oob, zchunk, r);
+    hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP, SOR>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout,
+                       pmid, bricks, bk, g, p_oob, zchunk, r, omega);
     return hipSuccess;
 }
 
