@@ -86,8 +86,8 @@ typedef enum fluid_image_id {
 
 typedef enum fluid_buffer_id {
     FLUID_BUF_PARTICLES_BUF = 0,
-    FLUID_BUF_MARCHING_CUBES_COUNTS_BUF = 1, /* render only: FLUID_ERR_UNSUPPORTED */
-    FLUID_BUF_MARCHING_CUBES_EDGES_BUF = 2,  /* render only: FLUID_ERR_UNSUPPORTED */
+    FLUID_BUF_MARCHING_CUBES_COUNTS_BUF = 1, /* uint[256]: triangles per corner configuration; surface_prep  */
+    FLUID_BUF_MARCHING_CUBES_EDGES_BUF = 2,  /* uint[256 * 15]: their edge indices (marching_cubes.h:24-33)    */
     FLUID_BUF_SIMULATION_PARAMS_BUF = 3,
     FLUID_BUFFER_COUNT = 4
 } fluid_buffer_id;
@@ -551,6 +551,18 @@ int fluid_pressure_residual(fluid_ctx* ctx, int image_id, float* max_abs, double
  * its pressure becomes inf / NaN and 13_fix_divergence carries that into the velocities.  Float images only
  * (VELOCITIES_1/2 count all four components, PRESSURES_1/2, DIVERGENCES, PARTICLE_DENSITIES_FLOAT_1/2). */
 int fluid_count_nonfinite(fluid_ctx* ctx, int image_id, uint64_t* count);
+
+/* Offline visualisation: the triangles the reference's marching-cubes renderer draws from a
+ * float density image of the detailed grid (30-32 are render sections and stay with the caller; this is the
+ * geometry of 31_render_surface — render_surface.vert:19-25, render_surface.geom:45-103 — as a list).
+ * surface_prep contexts, after fluid_upload_buffer of FLUID_BUF_MARCHING_CUBES_COUNTS_BUF / _EDGES_BUF (what
+ * MarchingCubesBuffers::loadData reads from surface_render_data/, marching_cubes.h:30-33).  image_id =
+ * FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2 is what the reference draws (fluid_flow_sections.h:431).  12 floats per
+ * triangle: three vertices in simulation-cell units, then the flat normal (normalize() = v / sqrt(dot(v, v)),
+ * IEEE); the order of the list is unspecified.  *count = triangles found; the first `capacity` of them are
+ * written to host_triangles (call with capacity 0 to size the buffer).  Synchronous. */
+int fluid_extract_surface(fluid_ctx* ctx, int image_id, float* host_triangles, uint64_t capacity,
+                          uint64_t* count);
 
 /* Diagnostics (synchronises the stream). */
 typedef enum fluid_stat {

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -125,7 +126,39 @@ private:
     FlowDescriptorContext m_context;
 };
 
-// ClearValue of the reference's wrapper library: a float4 or a uint
+// MarchingCubesBuffers (marching_cubes.h:15-51): the two tables of the surface renderer, read from the same
+// text files (whitespace-separated unsigned numbers) and copied into MARCHING_CUBES_COUNTS_BUF /
+// MARCHING_CUBES_EDGES_BUF of a surface_prep context.  extractSurface() then gives the triangles
+// 31_render_surface draws (fluid_extract_surface): {p0, p1, p2, normal} x 3 floats each.
+class MarchingCubesBuffers {
+public:
+    void loadData(FlowDescriptorContext& ctx, const std::string& directory = "surface_render_data") {
+        loadFromFile(ctx, MARCHING_CUBES_COUNTS_BUF, directory + "/polygon_counts.txt", 256);
+        loadFromFile(ctx, MARCHING_CUBES_EDGES_BUF, directory + "/polygon_edge_indices.txt", 256 * 15);
+    }
+    static std::vector<float> extractSurface(FlowDescriptorContext& ctx,
+                                             ImageAttachments density = PARTICLE_DENSITIES_FLOAT_2) {
+        uint64_t n = 0;
+        ctx.check(fluid_extract_surface(ctx.handle(), density, nullptr, 0, &n));
+        std::vector<float> out(12 * n);
+        if (n) ctx.check(fluid_extract_surface(ctx.handle(), density, out.data(), n, &n));
+        return out;
+    }
+
+private:
+    static void loadFromFile(FlowDescriptorContext& ctx, BufferAttachments buffer, const std::string& filename,
+                             uint32_t size) {
+        std::vector<uint32_t> data;
+        data.reserve(size);
+        std::ifstream data_file(filename);
+        uint32_t a;
+        for (uint32_t i = 0; i < size && (data_file >> a); i++) data.push_back(a);
+        if (data.size() != size) throw FluidError(FLUID_ERR_SIZE_MISMATCH, filename + ": too few numbers");
+        ctx.check(fluid_upload_buffer(ctx.handle(), buffer, data.data(), 4ull * size));
+    }
+};
+
+// ClearValue of the reference's wrapper library: a float4 or a uint// ClearValue of the reference's wrapper library: a float4 or a uint
 struct ClearValue {
     uint32_t bits[4];
     ClearValue(float r, float g, float b, float a) {

@@ -678,3 +678,70 @@ void oracle_run_step(oracle_state* s) {
     oracle_13_fix_divergence(p, s->cell_types, s->pressures_2, s->velocities_1);             /* :314 */
     oracle_14_particles(p, s->velocities_1, s->particles, s->particle_capacity);             /* :327 */
 }
+
+/* ---- 31_render_surface: the geometry the marching-cubes renderer emits (render_surface.vert:19-25,
+ * render_surface.geom:45-103), as a triangle list instead of a rasterised strip.  One render cell per vertex
+ * index, fluid_surface_render_size = detailed extent - 1 per axis (simulation_constants.h); corner i of cell
+ * pos is pos + moves[i] (:50); configuration bit i = density(corner i) > 0 (:93); counts[configuration]
+ * triangles, the vertex on edge e = vertex_edge_indices[configuration * 15 + 3 t + i] (:60-66):
+ *     a = d[e0] / (d[e0] - d[e1]);  point = (vec3(0.5) + pos + moves[e0] + (moves[e1] - moves[e0]) * a) / res
+ * and the flat normal normalize(cross(p1 - p0, p2 - p0)) (:69).  GLSL leaves normalize()'s precision open; it is
+ * DEFINED here as v / sqrt(dot(v, v)) with IEEE sqrt and division, dot = (x*x + y*y) + z*z (parity unpinned,
+ * like the sampler).  Output: 12 floats per triangle {p0, p1, p2, N}, cells in vertex-index order (x fastest);
+ * *count = triangles found, of which the first `capacity` are stored. */
+void oracle_31_extract_surface(const fluid_params* p, const float* density, const uint32_t* counts,
+                               const uint32_t* edge_indices, float* out, uint64_t capacity, uint64_t* count) {
+    static const int mv[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0},
+                                 {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    static const int ed[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                  {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    const int res = p->detailed_resolution;
+    const int W = (int)p->fluid_size[0] * res, H = (int)p->fluid_size[1] * res, D = (int)p->fluid_size[2] * res;
+    const float fres = (float)res;
+    uint64_t n = 0;
+    for (int z = 0; z < D - 1; z++)
+        for (int y = 0; y < H - 1; y++)
+            for (int x = 0; x < W - 1; x++) {
+                float d[8];
+                int cfg = 0;
+                for (int i = 0; i < 8; i++) {
+                    d[i] = density[(uint64_t)(x + mv[i][0]) +
+                                   (uint64_t)W * ((uint64_t)(y + mv[i][1]) + (uint64_t)H * (uint64_t)(z + mv[i][2]))];
+                    cfg |= (d[i] > 0.0f ? 1 : 0) << i;
+                }
+                const uint32_t tris = counts[cfg];
+                for (uint32_t t = 0; t < tris; t++) {
+                    float pt[3][3];
+                    for (int i = 0; i < 3; i++) {
+                        const uint32_t e = edge_indices[cfg * 15 + 3 * t + i];
+                        const int e0 = ed[e][0], e1 = ed[e][1];
+                        const float a = d[e0] / (d[e0] - d[e1]);
+                        const float cell[3] = {(float)x, (float)y, (float)z};
+                        for (int c = 0; c < 3; c++) {
+                            float v = 0.5f + cell[c];
+                            v = v + (float)mv[e0][c];
+                            v = v + (float)(mv[e1][c] - mv[e0][c]) * a;
+                            pt[i][c] = v / fres;
+                        }
+                    }
+                    float u[3], w[3], c3[3];
+                    for (int c = 0; c < 3; c++) {
+                        u[c] = pt[1][c] - pt[0][c];
+                        w[c] = pt[2][c] - pt[0][c];
+                    }
+                    c3[0] = u[1] * w[2] - w[1] * u[2];
+                    c3[1] = u[2] * w[0] - w[2] * u[0];
+                    c3[2] = u[0] * w[1] - w[0] * u[1];
+                    const float len = sqrtf((c3[0] * c3[0] + c3[1] * c3[1]) + c3[2] * c3[2]);
+                    if (n < capacity) {
+                        float* o = out + 12 * n;
+                        for (int i = 0; i < 3; i++)
+                            for (int c = 0; c < 3; c++) o[3 * i + c] = pt[i][c];
+                        for (int c = 0; c < 3; c++) o[9 + c] = c3[c] / len;
+                    }
+                    n++;
+                }
+            }
+    *count = n;
+}
+

@@ -89,6 +89,12 @@ void oracle_18_diffuse_float_densities(const fluid_params* p, const uint8_t* typ
 void oracle_18_diffuse_float_densities_loop(const fluid_params* p, const uint8_t* types, float* f1,
                                             float* f2, uint32_t iterations);
 
+/* 31_render_surface as a triangle list (render_surface.vert:19-25, render_surface.geom:45-103): 12 floats per
+ * triangle {p0, p1, p2, N}; counts[256] / edge_indices[256 * 15] = the reference's
+ * surface_render_data/polygon_counts.txt / polygon_edge_indices.txt (marching_cubes.h:30-33) */
+void oracle_31_extract_surface(const fluid_params* p, const float* density, const uint32_t* counts,
+                               const uint32_t* edge_indices, float* out, uint64_t capacity, uint64_t* count);
+
 /* sampler exposed for the known-answer tests: component `comp` of the trilinear sample at world
  * position (px,py,pz) as advect.comp:52-56 / particles.comp:28-36 take it */
 float oracle_sample_velocity_component(const fluid_params* p, const float* v, float px, float py,

@@ -70,6 +70,7 @@ def lib():
         "oracle_17_compute_float_densities": [pp, vp, vp],
         "oracle_18_diffuse_float_densities": [pp, vp, vp, vp, u32],
         "oracle_18_diffuse_float_densities_loop": [pp, vp, vp, vp, u32],
+        "oracle_31_extract_surface": [pp, vp, vp, vp, vp, u64, C.POINTER(u64)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -256,6 +257,20 @@ class OracleState:
             self.run_section(s)
         if self.surface_prep:
             self.run_surface_prep()
+
+    def extract_surface(self, density: np.ndarray, counts: np.ndarray, edge_indices: np.ndarray) -> np.ndarray:
+        """oracle_31_extract_surface: (n, 4, 3) — three vertices and the flat normal per triangle, cells in
+        vertex-index order."""
+        counts = np.ascontiguousarray(counts, np.uint32)
+        edge_indices = np.ascontiguousarray(edge_indices, np.uint32)
+        density = np.ascontiguousarray(density, np.float32)
+        n = C.c_uint64(0)
+        lib().oracle_31_extract_surface(self._p, _ptr(density), _ptr(counts), _ptr(edge_indices), None, 0,
+                                        C.byref(n))
+        out = np.empty((int(n.value), 4, 3), np.float32)
+        lib().oracle_31_extract_surface(self._p, _ptr(density), _ptr(counts), _ptr(edge_indices), _ptr(out),
+                                        out.shape[0], C.byref(n))
+        return out
 
     def sample(self, field: np.ndarray, px: float, py: float, pz: float, comp: int) -> float:
         return float(lib().oracle_sample_velocity_component(self._p, _ptr(field), px, py, pz, comp))

@@ -154,3 +154,46 @@ def test_cpp_section_lists_with_surface_prep(tmp_path):
     assert_bit_equal(got.reshape(st.detailed_shape), st.float_densities_1, "C++ float densities")
     got = np.fromfile(os.path.join(str(tmp_path), "particles.bin"), dtype=np.float32)
     assert_bit_equal(got.reshape(st.particles.shape), st.particles, "C++ particles")
+
+
+def test_surface_extraction_matches_oracle_triangles():
+    """the triangles of the reference's marching-cubes surface (31_render_surface) from a
+    float density image of the detailed grid — a bumpy ball and a noisy slab with exact zeros,
+    uploaded as PARTICLE_DENSITIES_FLOAT_2 / _1 — the engine's list (unordered) against the oracle's (cell
+    order), as sorted sets, bit for bit; tables through MARCHING_CUBES_COUNTS_BUF / _EDGES_BUF."""
+    import os
+    from fluid_amd import engine as E
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "marching_cubes_tables.npz"))
+    counts, edges = g["counts"], g["edge_indices"]
+    p, cap = fluid_amd.dam_break_params(16, 12, 8)
+    st = OracleState(p, cap, 2, surface_prep=True)
+    d, h, w = st.detailed_shape          # 40 x 60 x 80
+    z, y, x = np.meshgrid(np.arange(d), np.arange(h), np.arange(w), indexing="ij")
+    ball = (17.3 - np.sqrt((x - 40.2) ** 2 + (y - 28.7) ** 2 + (z - 19.1) ** 2)
+            + 2.5 * np.sin(0.7 * x) * np.cos(0.9 * y + 0.3 * z)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    slab = (np.float32(9.5) - y + rng.standard_normal((d, h, w)) * 0.8).astype(np.float32)
+    slab[rng.uniform(0, 1, slab.shape) < 0.01] = 0.0      # exact zeros: d > 0 is false there
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=2, surface_prep=True) as eng:
+        with pytest.raises(fluid_amd.FluidEngineError, match="upload MARCHING_CUBES"):
+            eng.extract_surface()
+        eng.upload_marching_cubes_tables(counts, edges)
+        eng.upload_image(E.PARTICLE_DENSITIES_FLOAT_2, ball)
+        eng.upload_image(E.PARTICLE_DENSITIES_FLOAT_1, slab)
+
+        def canon(t):
+            rows = np.ascontiguousarray(t.reshape(len(t), 12)).view(np.uint32)
+            return rows[np.lexsort(rows.T[::-1])]
+        for img, field in ((E.PARTICLE_DENSITIES_FLOAT_2, ball), (E.PARTICLE_DENSITIES_FLOAT_1, slab)):
+            got = eng.extract_surface(img)
+            exp = st.extract_surface(field, counts, edges)
+            assert got.shape == exp.shape and got.shape[0] > 5000
+            assert np.array_equal(canon(got), canon(exp))
+        assert eng.extract_surface().shape == eng.extract_surface(E.PARTICLE_DENSITIES_FLOAT_2).shape
+        bad = counts.copy()
+        bad[7] = 9
+        with pytest.raises(fluid_amd.FluidEngineError, match="out of range"):
+            eng.upload_marching_cubes_tables(bad, edges)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap) as plain:
+        with pytest.raises(fluid_amd.FluidEngineError):
+            plain.upload_marching_cubes_tables(counts, edges)

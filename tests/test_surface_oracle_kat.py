@@ -100,3 +100,58 @@ def test_loop_and_step_order():
     for f in OracleState.SURFACE_FIELDS:
         assert np.array_equal(getattr(st, f).view(np.uint32), getattr(ref, f).view(np.uint32)), f
     assert np.count_nonzero(st.detailed_densities) > 0 and np.count_nonzero(st.float_densities_1 > 0) > 0
+
+
+def mc_tables():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "marching_cubes_tables.npz"))
+    return g["counts"], g["edge_indices"]
+
+
+def test_marching_cubes_tables_are_consistent():
+    counts, edges = mc_tables()
+    assert counts.shape == (256,) and edges.shape == (3840,)
+    assert counts[0] == 0 and counts[255] == 0 and counts.max() == 5
+    assert int(counts.sum()) == 820     # the classic table (Lorensen & Cline's cases as tabulated by Bourke)
+    assert all(counts[1 << i] == 1 and counts[255 - (1 << i)] == 1 for i in range(8))  # one corner: one triangle
+    for c in range(256):
+        row = edges[15 * c:15 * c + 15]
+        assert np.all(row[:3 * counts[c]] < 12) and np.all(row[3 * counts[c]:] == 255)
+
+
+def test_kat_marching_cubes_one_corner_inside():
+    """render_surface.geom:60-69 by hand: a single detailed-grid corner with positive density (configuration
+    1 of the cell whose corner 0 it is) gives one triangle on the edges 0, 8, 3 = towards +x, +z, +y, each
+    vertex where the density crosses zero: a = d0 / (d0 - d1); the other seven cells around that corner see
+    it as another of their corners and cut it off likewise: eight triangles, an octahedron around it."""
+    from oracle_binding import OracleState
+    import fluid_amd
+    counts, edges = mc_tables()
+    p = fluid_amd.default_params(2, 2, 2, 0)
+    p.detailed_resolution = 2
+    st = OracleState(p, 0, 1)
+    d = np.full((4, 4, 4), -1.0, np.float32)
+    d[1, 1, 1] = 3.0          # inside; all neighbours -1: the crossing lies 3/4 of the way to each neighbour
+    tris = st.extract_surface(d, counts, edges)
+    assert tris.shape == (8, 4, 3)
+    # the cell whose corner 0 is (1, 1, 1): vertex-index order puts it last
+    t = tris[-1]
+    base = (0.5 + 1.0)
+    exp = np.array([[base + 0.75, base, base], [base, base, base + 0.75], [base, base + 0.75, base]],
+                   np.float32) / np.float32(2.0)
+    assert np.array_equal(t[:3], exp)
+    n = np.cross(t[1] - t[0], t[2] - t[0])
+    assert np.allclose(t[3], n / np.linalg.norm(n), atol=1e-6) and abs(np.linalg.norm(t[3]) - 1) < 1e-6
+    # all 24 vertices lie at distance 0.75 / res from the inside corner's render position
+    centre = np.float32((0.5 + 1.0) / 2.0)
+    dist = np.linalg.norm(tris[:, :3].reshape(-1, 3) - centre, axis=1)
+    assert np.allclose(dist, 0.375, atol=1e-6)
+    # capacity smaller than the count: counted, not stored
+    import ctypes as C
+    from oracle_binding import lib
+    nn = C.c_uint64(0)
+    few = np.zeros((3, 4, 3), np.float32)
+    lib().oracle_31_extract_surface(C.byref(st.params), d.ctypes.data, counts.ctypes.data, edges.ctypes.data,
+                                    few.ctypes.data, 3, C.byref(nn))
+    assert nn.value == 8 and np.array_equal(few, tris[:3])
+

@@ -91,6 +91,8 @@ struct fluid_ctx {
     uint32_t surface_steps = 4;
     uint32_t surface_dispatch_index = 0;  // loop counter of the 18_diffuse_float_densities section
     bool surface_fuse17 = false;          // inside fluid_run_step: 16 also writes what 17 would
+    uint32_t* mc_tables = nullptr;        // MARCHING_CUBES_COUNTS_BUF (256 words) + _EDGES_BUF (256 * 15)
+    bool mc_loaded[2] = {false, false};
     template <typename T>
     T* surf(int image_id) const {
         return reinterpret_cast<T*>(arena + surf_offset[image_id - 8]);
@@ -1305,6 +1307,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->ev_edges_done) (void)hipEventDestroy(c->ev_edges_done);
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->wide) (void)hipFree(c->wide);
+    if (c->mc_tables) (void)hipFree(c->mc_tables);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1331,9 +1334,14 @@ int fluid_buffer_bytes(const fluid_ctx* c, int buffer_id, uint64_t* bytes) {
         case FLUID_BUF_SIMULATION_PARAMS_BUF:
             *bytes = FLUID_PARAMS_BYTES;
             return FLUID_OK;
-        case FLUID_BUF_MARCHING_CUBES_COUNTS_BUF:
-        case FLUID_BUF_MARCHING_CUBES_EDGES_BUF:
-            return FLUID_ERR_UNSUPPORTED;
+        case FLUID_BUF_MARCHING_CUBES_COUNTS_BUF:  // marching_cubes.h:24-27: 4 bytes x 256 configurations
+            if (!c->surface) return FLUID_ERR_UNSUPPORTED;
+            *bytes = 4 * 256;
+            return FLUID_OK;
+        case FLUID_BUF_MARCHING_CUBES_EDGES_BUF:   // 4 bytes x 15 indices x 256 configurations
+            if (!c->surface) return FLUID_ERR_UNSUPPORTED;
+            *bytes = 4 * 15 * 256;
+            return FLUID_OK;
         default:
             return FLUID_ERR_INVALID_ARG;
     }
@@ -1405,6 +1413,25 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
                        buffer_id, (unsigned long long)want, (unsigned long long)bytes);
     if (buffer_id == FLUID_BUF_SIMULATION_PARAMS_BUF) return fluid_set_params(c, host);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (buffer_id == FLUID_BUF_MARCHING_CUBES_COUNTS_BUF || buffer_id == FLUID_BUF_MARCHING_CUBES_EDGES_BUF) {
+        // MarchingCubesBuffers::loadData (marching_cubes.h:30-33): the two tables, validated on the way in
+        const uint32_t* w = static_cast<const uint32_t*>(host);
+        const bool is_counts = buffer_id == FLUID_BUF_MARCHING_CUBES_COUNTS_BUF;
+        for (uint64_t i = 0; i < bytes / 4; i++)
+            if (is_counts ? w[i] > 5u : (w[i] > 11u && w[i] != 255u))
+                return c->fail(FLUID_ERR_INVALID_ARG, "marching-cubes table entry %llu = %u is out of range",
+                               (unsigned long long)i, w[i]);
+        if (!c->mc_tables) {
+            void* ptr = nullptr;
+            HIP_TRY(c, hipMalloc(&ptr, 4 * 256 * 16));
+            c->mc_tables = static_cast<uint32_t*>(ptr);
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->mc_tables + (is_counts ? 0 : 256), host, bytes, hipMemcpyHostToDevice,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->mc_loaded[is_counts ? 0 : 1] = true;
+        return FLUID_OK;
+    }
     if (bytes) {
         HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
         if (c->is_slab) {  // the caller passes the global array: keep what this slab owns
@@ -1431,6 +1458,14 @@ int fluid_download_buffer(fluid_ctx* c, int buffer_id, void* host, uint64_t byte
         return FLUID_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (buffer_id == FLUID_BUF_MARCHING_CUBES_COUNTS_BUF || buffer_id == FLUID_BUF_MARCHING_CUBES_EDGES_BUF) {
+        const bool is_counts = buffer_id == FLUID_BUF_MARCHING_CUBES_COUNTS_BUF;
+        if (!c->mc_loaded[is_counts ? 0 : 1]) return c->fail(FLUID_ERR_INVALID_ARG, "table not uploaded yet");
+        HIP_TRY(c, hipMemcpyAsync(host, c->mc_tables + (is_counts ? 0 : 256), bytes, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return FLUID_OK;
+    }
     if (bytes) {
         HIP_TRY(c, hipMemcpyAsync(host, c->particles(), bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2103,6 +2138,47 @@ int fluid_count_nonfinite(fluid_ctx* c, int image_id, uint64_t* count) {
     return FLUID_OK;
 }
 
+int fluid_extract_surface(fluid_ctx* c, int image_id, float* host_triangles, uint64_t capacity,
+                          uint64_t* count) {
+    if (!c) return FLUID_ERR_INVALID_ARG;
+    if (!count) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
+    if (!c->surface)
+        return c->fail(FLUID_ERR_UNSUPPORTED, "surface extraction needs a surface_prep context");
+    if (image_id != FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1 && image_id != FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2)
+        return c->fail(FLUID_ERR_INVALID_ARG, "image %d is not a float density image", image_id);
+    if (!c->mc_loaded[0] || !c->mc_loaded[1])
+        return c->fail(FLUID_ERR_INVALID_ARG,
+                       "upload MARCHING_CUBES_COUNTS_BUF and MARCHING_CUBES_EDGES_BUF first (the reference's "
+                       "surface_render_data/polygon_counts.txt / polygon_edge_indices.txt)");
+    if (capacity && !host_triangles) return c->fail(FLUID_ERR_INVALID_ARG, "null triangle buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    void* dev = nullptr;  // triangles + the counter behind them
+    const uint64_t tri_bytes = capacity * 48;
+    if (hipMalloc(&dev, tri_bytes + 8) != hipSuccess)
+        return c->fail(FLUID_ERR_OUT_OF_MEMORY, "%llu bytes for the triangle list",
+                       (unsigned long long)(tri_bytes + 8));
+    auto* total = reinterpret_cast<unsigned long long*>(static_cast<char*>(dev) + tri_bytes);
+    int rc = FLUID_OK;
+    unsigned long long found = 0;
+    const SurfK& s = c->sk;
+    hipError_t e = hipMemsetAsync(total, 0, 8, c->stream);
+    if (e == hipSuccess && s.W > 1 && s.H > 1 && s.D > 1) {
+        hipLaunchKernelGGL(k31_extract_surface, dim3((s.W - 1 + 63) / 64, (s.H - 1 + 3) / 4, s.D - 1),
+                           dim3(64, 4, 1), 0, c->stream, c->surf<float>(image_id), s, c->mc_tables,
+                           c->mc_tables + 256, static_cast<float*>(dev), (unsigned long long)capacity, total);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&found, total, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    const uint64_t stored = std::min<uint64_t>(found, capacity);
+    if (e == hipSuccess && stored)
+        e = hipMemcpy(host_triangles, dev, stored * 48, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = c->fail(FLUID_ERR_HIP, "surface extraction: %s", hipGetErrorString(e));
+    (void)hipFree(dev);
+    *count = found;
+    return rc;
+}
+
 int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!value) return c->fail(FLUID_ERR_INVALID_ARG, "null output pointer");
@@ -2186,6 +2262,7 @@ int fluid_sampler_wide_begin(fluid_ctx* c, uint32_t below, uint32_t above) {
     if (bytes > c->wide_bytes) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->wide) (void)hipFree(c->wide);
+    if (c->mc_tables) (void)hipFree(c->mc_tables);
         c->wide = nullptr;
         c->wide_bytes = 0;
         void* ptr = nullptr;

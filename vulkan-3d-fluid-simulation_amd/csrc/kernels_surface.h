@@ -334,4 +334,65 @@ k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const floa
     }
 }
 
+// ---- 31_render_surface as a triangle list (offline visualisation) -------------------
+// What the reference's marching-cubes geometry shader emits (render_surface.vert:19-25, render_surface.geom:
+// 45-103), stored instead of rasterised: one thread per render cell ((W-1) x (H-1) x (D-1) cells of the
+// detailed grid), configuration bit i = density(corner i) > 0, counts[configuration] triangles whose vertices
+// lie on the cell edges named by edge_indices[configuration * 15 + ...] at a = d0 / (d0 - d1), flat normal
+// v / sqrt(dot(v, v)) of cross(p1 - p0, p2 - p0) (normalize() as defined in oracle_31_extract_surface).
+// 12 floats per triangle {p0, p1, p2, N}, appended through one atomic per cell with triangles: the order of
+// the list is not defined (the reference draws, it does not order either).  Triangles beyond `capacity` are
+// counted, not stored.
+__global__ void k31_extract_surface(const float* __restrict__ density, SurfK s,
+                                    const uint32_t* __restrict__ counts,
+                                    const uint32_t* __restrict__ edge_indices, float* __restrict__ out,
+                                    unsigned long long capacity, unsigned long long* __restrict__ total) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = blockIdx.z;
+    if (x >= s.W - 1 || y >= s.H - 1) return;
+    const int mv[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    const int ed[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    float d[8];
+    int cfg = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d[i] = density[sidx(s, x + mv[i][0], y + mv[i][1], z + mv[i][2])];
+        cfg |= (d[i] > 0.0f ? 1 : 0) << i;  // :93
+    }
+    const uint32_t tris = counts[cfg];
+    if (tris == 0) return;
+    const unsigned long long first = atomicAdd(total, (unsigned long long)tris);
+    const float fres = (float)s.res;
+    const float cell[3] = {(float)x, (float)y, (float)z};
+    for (uint32_t t = 0; t < tris; t++) {
+        if (first + t >= capacity) return;
+        float pt[3][3];
+        for (int i = 0; i < 3; i++) {
+            const uint32_t e = edge_indices[cfg * 15 + 3 * t + i];  // :60
+            const int e0 = ed[e][0], e1 = ed[e][1];
+            const float a = d[e0] / (d[e0] - d[e1]);                 // :64
+            for (int c = 0; c < 3; c++) {
+                float v = 0.5f + cell[c];                            // :66, left to right
+                v = v + (float)mv[e0][c];
+                v = v + (float)(mv[e1][c] - mv[e0][c]) * a;
+                pt[i][c] = v / fres;
+            }
+        }
+        float u[3], w[3], c3[3];
+        for (int c = 0; c < 3; c++) {
+            u[c] = pt[1][c] - pt[0][c];
+            w[c] = pt[2][c] - pt[0][c];
+        }
+        c3[0] = u[1] * w[2] - w[1] * u[2];  // cross(), :69
+        c3[1] = u[2] * w[0] - w[2] * u[0];
+        c3[2] = u[0] * w[1] - w[0] * u[1];
+        const float len = sqrtf((c3[0] * c3[0] + c3[1] * c3[1]) + c3[2] * c3[2]);
+        float* o = out + 12ull * (first + t);
+        for (int i = 0; i < 3; i++)
+            for (int c = 0; c < 3; c++) o[3 * i + c] = pt[i][c];
+        for (int c = 0; c < 3; c++) o[9 + c] = c3[c] / len;
+    }
+}
+
 }  // namespace fluid

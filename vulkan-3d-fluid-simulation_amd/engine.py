@@ -88,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "fluid_set_sampler_halo", "fluid_sampler_reach", "fluid_sampler_wide_begin",
     "fluid_sampler_wide_plane_ptr", "fluid_run_advect_wide",
     "fluid_step_begin", "fluid_step_end", "fluid_step_build_activity", "fluid_activity_layer_ptr",
-    "fluid_step_status", "fluid_step_set_box",
+    "fluid_step_status", "fluid_step_set_box", "fluid_extract_surface",
 ]
 
 
@@ -196,6 +196,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_activity_layer_ptr": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_step_status": (C.c_int, [vp, C.POINTER(u32 * 8)]),
         "fluid_step_set_box": (C.c_int, [vp, C.c_int, u32, u32, u32, u32, u32]),
+        "fluid_extract_surface": (C.c_int, [vp, C.c_int, vp, u64, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -580,6 +581,25 @@ class FluidEngine:
         self._check(self._lib.fluid_pressure_residual(self._h, image_id, C.byref(m), C.byref(s),
                                                       C.byref(n)))
         return float(m.value), float(s.value), int(n.value)
+
+    def upload_marching_cubes_tables(self, counts, edge_indices):
+        """MarchingCubesBuffers::loadData (marching_cubes.h:30-33): uint[256] and uint[256 * 15]."""
+        for buf, arr, n in ((MARCHING_CUBES_COUNTS_BUF, counts, 256), (MARCHING_CUBES_EDGES_BUF, edge_indices, 3840)):
+            a = np.ascontiguousarray(arr, dtype=np.uint32).reshape(-1)
+            if a.size != n:
+                raise FluidEngineError(ERR_SIZE_MISMATCH, f"buffer {buf} holds {n} entries, got {a.size}")
+            self._check(self._lib.fluid_upload_buffer(self._h, buf, a.ctypes.data, a.nbytes))
+
+    def extract_surface(self, image_id: int = PARTICLE_DENSITIES_FLOAT_2) -> np.ndarray:
+        """The triangles of the reference's marching-cubes surface as an (n, 4, 3) array: three vertices and
+        the flat normal per triangle (include/fluid_engine.h: fluid_extract_surface)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.fluid_extract_surface(self._h, image_id, None, 0, C.byref(n)))
+        out = np.empty((int(n.value), 4, 3), np.float32)
+        if out.size:
+            self._check(self._lib.fluid_extract_surface(self._h, image_id, out.ctypes.data, out.shape[0],
+                                                        C.byref(n)))
+        return out
 
     def count_nonfinite(self, image_id: int) -> int:
         """inf / NaN words in the owned planes of a float image (include/fluid_engine.h)."""
