@@ -12,7 +12,8 @@ from oracle_binding import OracleState
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz")))
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN)
+                                        if f.endswith(".npz") and f != "marching_cubes_tables.npz"))  # data, not a vector
 def test_oracle_reproduces_golden(name):
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))

@@ -21,12 +21,16 @@ for path in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recur
             if "k12_canon2" in r["Kernel_Name"]:
                 vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
-avg_ns = None
+avg_ns = None   # over all template variants of the kernel (the last pair of a loop is the KEEP one), like the counters
+tot_ns = calls = 0.0
 for path in glob.glob(os.path.join(src, "stats", "*kernel_stats.csv")):
     with open(path) as f:
         for r in csv.DictReader(f):
             if "k12_canon2" in r["Name"]:
-                avg_ns = float(r["AverageNs"])
+                tot_ns += float(r["TotalDurationNs"])
+                calls += float(r["Calls"])
+if calls:
+    avg_ns = tot_ns / calls
 rd = mean["TCC_EA0_RDREQ_sum"] * 128.0
 wr = mean["WRITE_SIZE"] * 1024.0
 rec = {"kernel": "k12_canon2", "grid": grid,

@@ -22,4 +22,4 @@ def summarise(root):
 
 if __name__ == "__main__":
     for k, c, n, mean, lo, hi in summarise(sys.argv[1]):
-        print(f"{k[:60]:60s} {c:24s} n={n:5d} mean={mean:16.1f} min={lo:16.1f} max={hi:16.1f}")
+        print(f"{k[:100]:100s} {c:24s} n={n:5d} mean={mean:16.1f} min={lo:16.1f} max={hi:16.1f}")
