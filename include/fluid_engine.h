@@ -531,6 +531,13 @@ typedef enum fluid_option {
     FLUID_OPT_EDGE_STREAM = 7,     /* split passes of the explicit loop API: 0 = both launches on the       */
                                    /* context's stream (default), 1 = EDGES on a second stream (see        */
                                    /* fluid_pressure_loop_advance_part)                                    */
+    FLUID_OPT_PARTICLE_SORT = 8,   /* whole-grid contexts: the particles are STORED sorted by bins of 16 x 4 x  */
+                                   /* 16 cells (01 becomes an LDS histogram with plain stores, 14 takes its    */
+                                   /* taps from an LDS tile); uploads, downloads and 00 keep speaking slot      */
+                                   /* order, so nothing is observable but the time.  0 = on from 4 M particle   */
+                                   /* slots (default; needs 28 B per slot outside the arena, falls back to slot */
+                                   /* order if that cannot be allocated), 1 = off, 2 = on at any size; 3 / 4 =   */
+                                   /* test modes (sort before every 01 / sort once and never again)             */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
@@ -567,7 +574,9 @@ int fluid_extract_surface(fluid_ctx* ctx, int image_id, float* host_triangles, u
 /* Diagnostics (synchronises the stream). */
 typedef enum fluid_stat {
     FLUID_STAT_BRICKS = 0,       /* activity bricks of this context (256 x 4 x 16 cells each)          */
-    FLUID_STAT_QUIET_BRICKS = 1  /* bricks the last fluid_run_step skipped in 07+08, 09+10+11 and 13   */
+    FLUID_STAT_QUIET_BRICKS = 1, /* bricks the last fluid_run_step skipped in 07+08, 09+10+11 and 13   */
+    FLUID_STAT_PARTICLE_SORTS = 2,   /* sorts of the particle storage so far (FLUID_OPT_PARTICLE_SORT)     */
+    FLUID_STAT_PARTICLE_STRAYS = 3   /* particles the last 01 found outside the bin they are stored in     */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 

@@ -1,0 +1,135 @@
+"""Particles stored sorted by bin (FLUID_OPT_PARTICLE_SORT, csrc/kernels_particle_bins.h): 01_update_densities
+as an LDS histogram per bin, 14_particles with an LDS velocity tile per bin, strays, the counting sort, the
+slot bookkeeping.  Nothing of it may be observable: every image and the particle buffer in SLOT order stay
+bit-identical to the oracle (update_densities.comp:29-36, particles.comp:45-51)."""
+import numpy as np
+import pytest
+
+import fluid_amd
+from fluid_amd import engine as E
+from fluid_amd.params import dam_break_params, default_params
+from helpers import assert_bit_equal, assert_state_equal, make_engine, random_state
+from oracle_binding import OracleState
+
+pytestmark = pytest.mark.gpu
+
+SORT_ON, SORT_EVERY_STEP, SORT_ONCE = 2, 3, 4
+
+
+@pytest.mark.parametrize("size", [(24, 20, 16), (17, 13, 9), (64, 8, 5), (5, 5, 5), (260, 6, 40)])
+def test_sorted_particle_sections_match_oracle(size):
+    """Single sections on random scenes (particles inside, on the edge of and outside the grid, inactive
+    ones): 01 onto an image that was NOT cleared (the binned kernel must add, update_densities.comp:35),
+    01a + 01, 14, and again after the particles have moved (strays)."""
+    st = random_state(size, capacity=5000, seed=sum(size))
+    with make_engine(st) as eng:
+        eng.set_option(E.OPT_PARTICLE_SORT, SORT_ONCE)
+        for section in ("01_update_densities", "01a_clear_particle_densities", "01_update_densities",
+                        "14_particles", "14_particles", "01a_clear_particle_densities",
+                        "01_update_densities", "01_update_densities", "14_particles"):
+            eng.run_section(section)
+            st.run_section(section)
+            assert_state_equal(eng, st, fields=["particle_densities", "particles"], ctx=f"{section} {size}: ")
+        assert eng.get_stat(E.STAT_PARTICLE_SORTS) == 1
+        if min(size) > 5:
+            assert eng.get_stat(E.STAT_PARTICLE_STRAYS) > 0   # |v| ~ 3 cells/s * dt moved some out of their bins
+
+
+@pytest.mark.parametrize("mode", [SORT_ON, SORT_EVERY_STEP, SORT_ONCE])
+def test_sorted_full_steps_match_oracle(mode):
+    size, iters, steps = (64, 64, 96), 6, 8
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.set_option(E.OPT_PARTICLE_SORT, mode)
+        eng.run_init()
+        st.run_init()
+        for k in range(steps):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"mode {mode} step {k}: ")
+        sorts = eng.get_stat(E.STAT_PARTICLE_SORTS)
+        assert sorts == (steps if mode == SORT_EVERY_STEP else 1 if mode == SORT_ONCE else sorts) and sorts >= 1
+        # the API keeps speaking slot order: an upload in the middle of a run, then more steps
+        q = st.particles.copy()
+        q[::7, 1] += 0.25
+        q[5::11, 3] = 0.0            # some slots become inactive
+        eng.upload_particles(q)
+        st.particles[...] = q
+        for k in range(2):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"mode {mode} after upload, step {k}: ")
+        # switching it off returns the storage to slot order
+        eng.set_option(E.OPT_PARTICLE_SORT, 1)
+        eng.run_step()
+        st.run_step()
+        assert_state_equal(eng, st, ctx=f"mode {mode} switched off: ")
+
+
+def test_sorted_fast_drift_strays_and_resort():
+    """A blob carried 2-3 cells per step through a wide grid: most particles leave their bin between two
+    sorts (01 lists them, 14 takes their taps from global memory), and the engine sorts again on its own
+    once the strays pass a sixteenth of the slots."""
+    w, h, d = 320, 24, 48
+    cap = 20000
+    rng = np.random.default_rng(5)
+    p = default_params(w, h, d, cap)
+    p.time_delta = 0.05
+    p.particle_compute_size[:] = (cap, 1)
+    particles = np.zeros((cap, 4), np.float32)
+    particles[:, :3] = np.array([0.3 * w, 0.5 * h, 0.4 * d], np.float32) + \
+        rng.uniform(-1, 1, (cap, 3)).astype(np.float32) * np.array([30.0, 4.0, 6.0], np.float32)
+    particles[:, 3] = 1.0
+    drift = np.zeros((d, h, w, 4), np.float32)
+    drift[..., 0] = 50.0
+    drift[..., 2] = 7.0
+    iters = 8
+    st = OracleState(p, cap, iters)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
+        eng.set_option(E.OPT_PARTICLE_SORT, SORT_ON)
+        eng.run_init()
+        st.run_init()
+        eng.upload_particles(particles)
+        st.particles[...] = particles
+        eng.run_step()
+        st.run_step()
+        eng.upload_image(E.VELOCITIES_1, drift)
+        st.velocities_1[...] = drift
+        for k in range(10):
+            eng.run_step()
+            st.run_step()
+            assert_state_equal(eng, st, ctx=f"drift step {k}: ")
+        assert eng.get_stat(E.STAT_PARTICLE_SORTS) >= 3
+
+
+def test_sorted_particles_with_surface_prep_and_checkpoint(tmp_path):
+    """15_update_detailed_densities reads the particle buffer too (order-neutral atomics), and a checkpoint
+    taken from sorted storage resumes bit-identically."""
+    from test_surface_gpu import assert_surface_equal
+    size, iters = (24, 20, 16), 8
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters, surface_prep=True)
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters, surface_prep=True) as eng:
+        eng.set_option(E.OPT_PARTICLE_SORT, SORT_ON)
+        eng.run_init()
+        st.run_init()
+        for k in range(3):
+            eng.run_step()
+            st.run_step()
+        assert_state_equal(eng, st, ctx="before checkpoint: ")
+        assert_surface_equal(eng, st, "before checkpoint: ")
+        path = str(tmp_path / "ck")
+        eng.save_checkpoint(path)
+        for k in range(2):
+            eng.run_step()
+            st.run_step()
+        assert_state_equal(eng, st, ctx="after checkpoint: ")
+        after = eng.download_particles()
+    with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters, surface_prep=True) as eng:
+        eng.set_option(E.OPT_PARTICLE_SORT, SORT_ON)
+        eng.restore_checkpoint(path)
+        for k in range(2):
+            eng.run_step()
+        assert_state_equal(eng, st, ctx="resumed: ")
+        assert_bit_equal(eng.download_particles(), after, "resumed particles")

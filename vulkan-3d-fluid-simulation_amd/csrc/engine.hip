@@ -19,6 +19,7 @@
 #include "kernels_grid.h"
 #include "pressure_api.h"
 #include "kernels_sampler.h"
+#include "kernels_particle_bins.h"
 #include "kernels_step_fused.h"
 #include "kernels_surface.h"
 
@@ -73,6 +74,27 @@ struct fluid_ctx {
     GridK g{};
     uint64_t particle_capacity = 0;
     uint64_t particles_offset = 0;
+    // particles stored sorted by bin (kernels_particle_bins.h; whole-grid contexts, FLUID_OPT_PARTICLE_SORT).
+    // Everything here lives outside the arena and is allocated by the first sort.
+    struct ParticleSort {
+        float4* alt = nullptr;                   // the second particle buffer (a sort scatters into the other one)
+        uint32_t* slot_of[2] = {nullptr, nullptr};  // per buffer: the slot (index of the API) of each stored particle
+        uint32_t* bin_count = nullptr;           // bins + 2 words each
+        uint32_t* bin_start = nullptr;
+        uint32_t* cursor = nullptr;
+        uint32_t* strays = nullptr;              // cell indices, particle_capacity entries
+        uint32_t* stray_count = nullptr;         // [0] entries of `strays`, [1] particles found outside their bin
+        uint32_t* stray_host = nullptr;          // pinned copy of stray_count, one step behind
+        hipEvent_t stray_ev = nullptr;
+        bool stray_pending = false;
+        PBinK bk{};
+        int cur = 0;          // buffer that holds the particles: 0 = the arena's, 1 = alt
+        bool valid = false;   // ... sorted, slot_of[cur] and bin_start describe it
+        bool failed = false;  // an allocation failed: slot order from now on
+        uint64_t sorts = 0;
+        uint32_t last_strays = 0;
+    } ps;
+    bool dens_zero = false;  // PARTICLE_DENSITIES was cleared and nothing has counted into it since
     uint32_t pressure_iterations = 200;
     int diffuse_mode = FLUID_DIFFUSE_REFERENCE_EXACT;
     uint32_t pressure_dispatch_index = 0;  // loop counter of the 12_solve_pressure section
@@ -171,7 +193,8 @@ struct fluid_ctx {
         return reinterpret_cast<T*>(arena + img[image].offset +
                                     (uint64_t)IMG_GHOST * g.plane * img[image].elem_bytes);
     }
-    float4* particles() const { return reinterpret_cast<float4*>(arena + particles_offset); }
+    float4* particles_home() const { return reinterpret_cast<float4*>(arena + particles_offset); }
+    float4* particles() const { return ps.cur ? ps.alt : particles_home(); }  // where they are stored now
     // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
     uint8_t* mask0() const { return arena + mask_offset + (uint64_t)LOOP_GHOST * g.plane; }
     float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + LOOP_GHOST * g.plane; }
@@ -222,6 +245,8 @@ struct fluid_ctx {
             rhs_valid = false;
         } else if (image == FLUID_IMG_VELOCITIES_1) {
             v1_w_zero = false;
+        } else if (image == FLUID_IMG_PARTICLE_DENSITIES_IMG) {
+            dens_zero = false;
         }
     }
     uint64_t owned_cells() const { return (uint64_t)g.plane * (uint64_t)g.Dl; }
@@ -789,6 +814,143 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
                    what);
 }
 
+
+// ---- particles stored sorted by bin (kernels_particle_bins.h) -------------------------------------------
+// FLUID_OPT_PARTICLE_SORT: 0 = on for whole-grid contexts with at least 4 M particle slots, 1 = off,
+// 2 = on whatever the size, 3 = on and sorted again before every 01 (tests), 4 = on, sorted once and never
+// again (tests: strays pile up).
+bool psort_wanted(const fluid_ctx* c) {
+    const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
+    if (c->is_slab || c->ps.failed || c->particle_capacity == 0 || c->particle_capacity >= (1ull << 32) ||
+        mode == 1)
+        return false;
+    return mode >= 2 || c->particle_capacity >= (1ull << 22);
+}
+void psort_release(fluid_ctx* c) {
+    auto& ps = c->ps;
+    if (ps.alt) (void)hipFree(ps.alt);
+    for (auto*& q : ps.slot_of)
+        if (q) (void)hipFree(q), q = nullptr;
+    if (ps.bin_count) (void)hipFree(ps.bin_count);
+    if (ps.strays) (void)hipFree(ps.strays);
+    if (ps.stray_count) (void)hipFree(ps.stray_count);
+    if (ps.stray_host) (void)hipHostFree(ps.stray_host);
+    if (ps.stray_ev) (void)hipEventDestroy(ps.stray_ev);
+    ps.alt = nullptr;
+    ps.bin_count = ps.bin_start = ps.cursor = ps.strays = ps.stray_count = ps.stray_host = nullptr;
+    ps.stray_ev = nullptr;
+}
+// the particles are (again) in slot order in the arena's buffer: after 00_init_particles and uploads
+void psort_reset(fluid_ctx* c) {
+    c->ps.valid = false;
+    c->ps.cur = 0;
+    c->ps.stray_pending = false;
+    c->ps.last_strays = 0;
+}
+bool psort_alloc(fluid_ctx* c) {
+    auto& ps = c->ps;
+    if (ps.alt) return true;
+    ps.bk.nx = (c->g.W + PBIN_X - 1) / PBIN_X;
+    ps.bk.ny = (c->g.H + PBIN_Y - 1) / PBIN_Y;
+    ps.bk.nz = (c->g.Dg + PBIN_Z - 1) / PBIN_Z;
+    ps.bk.bins = (uint32_t)ps.bk.nx * (uint32_t)ps.bk.ny * (uint32_t)ps.bk.nz;
+    const uint64_t n = c->particle_capacity, words = (uint64_t)ps.bk.bins + 2;
+    void* q = nullptr;
+    bool ok = hipMalloc(&q, n * 16) == hipSuccess;
+    ps.alt = static_cast<float4*>(q);
+    for (int i = 0; ok && i < 2; i++) {
+        ok = hipMalloc(&q, n * 4) == hipSuccess;
+        ps.slot_of[i] = ok ? static_cast<uint32_t*>(q) : nullptr;
+    }
+    if (ok && (ok = hipMalloc(&q, 3 * words * 4) == hipSuccess)) {
+        ps.bin_count = static_cast<uint32_t*>(q);
+        ps.bin_start = ps.bin_count + words;
+        ps.cursor = ps.bin_start + words;
+    }
+    if (ok && (ok = hipMalloc(&q, n * 4) == hipSuccess)) ps.strays = static_cast<uint32_t*>(q);
+    if (ok && (ok = hipMalloc(&q, 8) == hipSuccess)) ps.stray_count = static_cast<uint32_t*>(q);
+    if (ok && (ok = hipHostMalloc(&q, 8, hipHostMallocDefault) == hipSuccess))
+        ps.stray_host = static_cast<uint32_t*>(q);
+    if (ok) ok = hipEventCreateWithFlags(&ps.stray_ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {  // not an error of the step: the particles simply stay in slot order
+        (void)hipGetLastError();
+        psort_release(c);
+        ps.failed = true;
+    }
+    return ok;
+}
+int psort_sort(fluid_ctx* c) {
+    auto& ps = c->ps;
+    const uint64_t n = c->particle_capacity, per_block = (uint64_t)PSORT_THREADS * PSORT_PER_THREAD;
+    const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+    const float4* in = c->particles();
+    const uint32_t* slot_in = ps.valid ? ps.slot_of[ps.cur] : nullptr;
+    const int dst = ps.cur ^ 1;
+    float4* out = dst ? ps.alt : c->particles_home();
+    HIP_TRY(c, hipMemsetAsync(ps.bin_count, 0, ((uint64_t)ps.bk.bins + 2) * 4, c->stream));
+    hipLaunchKernelGGL(k_pbin_histogram, dim3(blocks), dim3(PSORT_THREADS), 0, c->stream, in, n, c->g, c->pk,
+                       ps.bk, ps.bin_count);
+    hipLaunchKernelGGL(k_pbin_scan, dim3(1), dim3(1024), 0, c->stream, ps.bin_count, ps.bk.bins + 1,
+                       ps.bin_start, ps.cursor);
+    hipLaunchKernelGGL(k_pbin_scatter, dim3(blocks), dim3(PSORT_THREADS), 0, c->stream, in, slot_in, n, c->g,
+                       c->pk, ps.bk, ps.cursor, out, ps.slot_of[dst]);
+    HIP_TRY(c, hipGetLastError());
+    ps.cur = dst;
+    ps.valid = true;
+    ps.sorts++;
+    ps.stray_pending = false;
+    ps.last_strays = 0;
+    return FLUID_OK;
+}
+// before 01_update_densities: sort if the storage is not sorted yet, or if the last 01 found too many
+// particles outside their bins (read one step late, without waiting for it)
+int psort_before_count(fluid_ctx* c) {
+    auto& ps = c->ps;
+    if (!psort_wanted(c) || !psort_alloc(c)) {
+        if (ps.valid) {  // switched off while sorted: back to slot order
+            hipLaunchKernelGGL(k_pbin_to_slot_order, dim3((unsigned)((c->particle_capacity + 255) / 256)),
+                               dim3(256), 0, c->stream, c->particles(), ps.slot_of[ps.cur],
+                               c->particle_capacity, ps.cur ? c->particles_home() : ps.alt);
+            HIP_TRY(c, hipGetLastError());
+            if (!ps.cur) {  // the slot-ordered copy went to alt: bring it home
+                HIP_TRY(c, hipMemcpyAsync(c->particles_home(), ps.alt, c->particle_capacity * 16,
+                                          hipMemcpyDeviceToDevice, c->stream));
+            }
+            psort_reset(c);
+        }
+        return FLUID_OK;
+    }
+    if (ps.stray_pending && hipEventQuery(ps.stray_ev) == hipSuccess) {
+        ps.last_strays = ps.stray_host[1];
+        ps.stray_pending = false;
+    }
+    const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
+    const bool again = mode == 3 || (mode != 4 && (uint64_t)ps.last_strays * 16 > c->particle_capacity);
+    if (!ps.valid || again) return psort_sort(c);
+    return FLUID_OK;
+}
+// 01 on the sorted storage; `marks` = pbricks() or null
+int psort_count(fluid_ctx* c, uint32_t* dens, uint8_t* marks, const BrickK& bk) {
+    auto& ps = c->ps;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ps.bk.bins + 1, 256 * 64);
+    HIP_TRY(c, hipMemsetAsync(ps.stray_count, 0, 8, c->stream));
+    if (c->dens_zero)
+        hipLaunchKernelGGL(k01_binned<false>, dim3(blocks), dim3(256), 0, c->stream, c->particles(),
+                           ps.bin_start, ps.bk, dens, c->g, c->pk, marks, bk, ps.strays, ps.stray_count);
+    else
+        hipLaunchKernelGGL(k01_binned<true>, dim3(blocks), dim3(256), 0, c->stream, c->particles(),
+                           ps.bin_start, ps.bk, dens, c->g, c->pk, marks, bk, ps.strays, ps.stray_count);
+    hipLaunchKernelGGL(k01_binned_strays, dim3(1024), dim3(256), 0, c->stream, ps.strays, ps.stray_count, dens,
+                       c->g, marks, bk);
+    HIP_TRY(c, hipGetLastError());
+    if (!ps.stray_pending) {
+        HIP_TRY(c, hipMemcpyAsync(ps.stray_host, ps.stray_count, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(ps.stray_ev, c->stream));
+        ps.stray_pending = true;
+    }
+    return FLUID_OK;
+}
+
 // internal ids of the grouped passes, past the public section ids
 enum : int {
     STEP_0405_EXTRAPOLATE = FLUID_SECTION_COUNT + 1,
@@ -825,26 +987,39 @@ int run_section_impl(fluid_ctx* c, int section) {
             return fill_image(c, FLUID_IMG_CELL_TYPES, pk.t_inactive);
         case FLUID_SEC_00_INIT_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
+            psort_reset(c);  // slot order, in the arena's buffer
             hipLaunchKernelGGL(k00_init_particles, dim3(pblocks), dim3(256), 0, c->stream,
                                c->particles(), c->particle_capacity, pk, g, c->is_slab ? 1 : 0);
             break;
-        case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES:
-            return fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
+        case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES: {
+            const int rc = fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
+            c->dens_zero = rc == FLUID_OK;
+            return rc;
+        }
         case STEP_01A_CLEAR_WHERE_PARTICLES_WERE:  // quiet_bricks.h; bricks() and pbricks() still hold the
                                                    // previous step's water / particle maps
             hipLaunchKernelGGL(k_clear_density_where_particles_were, cell4_grid(g), block, 0, c->stream,
                                dens, g, c->bricks(), c->pbricks(), bk);
+            c->dens_zero = true;  // the other bricks have not been counted into since the last full clear
             break;
         case STEP_01_UPDATE_DENSITIES_MARK_BRICKS: {
             const int nb = (int)c->active_bytes;
             HIP_TRY(c, hipMemsetAsync(c->pbricks(), 0, c->active_bytes, c->stream));
             if (c->particle_capacity != 0) {
-                const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
-                const unsigned blocks =
-                    (unsigned)((c->particle_capacity + per_block - 1) / per_block);
-                hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
-                                   c->particles(), c->particle_capacity, dens, g, pk, c->pbricks(), bk);
+                int rc = psort_before_count(c);
+                if (rc) return rc;
+                if (c->ps.valid) {
+                    rc = psort_count(c, dens, c->pbricks(), bk);
+                    if (rc) return rc;
+                } else {
+                    const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
+                    const unsigned blocks =
+                        (unsigned)((c->particle_capacity + per_block - 1) / per_block);
+                    hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                                       c->particles(), c->particle_capacity, dens, g, pk, c->pbricks(), bk);
+                }
             }
+            c->dens_zero = false;
             c->pbricks_valid = true;
             if (c->early_wanted)
                 hipLaunchKernelGGL(k_update_early_quiet, dim3((nb + 255) / 256), dim3(256), 0, c->stream,
@@ -854,11 +1029,19 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_01_UPDATE_DENSITIES: {
             c->pbricks_valid = false;  // counted without marking the bricks
             if (c->particle_capacity == 0) return FLUID_OK;
-            const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
-            const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
-            hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
-                               c->particles(), c->particle_capacity, dens, g, pk,
-                               (uint8_t*)nullptr, bk);
+            int rc = psort_before_count(c);
+            if (rc) return rc;
+            if (c->ps.valid) {
+                rc = psort_count(c, dens, nullptr, bk);
+                if (rc) return rc;
+            } else {
+                const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
+                const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
+                hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                                   c->particles(), c->particle_capacity, dens, g, pk,
+                                   (uint8_t*)nullptr, bk);
+            }
+            c->dens_zero = false;
             break;
         }
         case FLUID_SEC_02_UPDATE_WATER:
@@ -1044,8 +1227,14 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_14_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
-            hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
-                               c->particles(), c->particle_capacity, g, pk, c->flags());
+            if (c->ps.valid) {
+                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)c->ps.bk.bins + 1, 256 * 64);
+                hipLaunchKernelGGL(k14_binned, dim3(blocks), dim3(256), 0, c->stream, V1, c->particles(),
+                                   c->ps.bin_start, c->ps.bk, g, pk, c->flags());
+            } else {
+                hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
+                                   c->particles(), c->particle_capacity, g, pk, c->flags());
+            }
             break;
         default:
             return c->fail(FLUID_ERR_INVALID_ARG, "unknown section id %d", section);
@@ -1307,6 +1496,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->ev_edges_done) (void)hipEventDestroy(c->ev_edges_done);
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->wide) (void)hipFree(c->wide);
+    psort_release(c);
     if (c->mc_tables) (void)hipFree(c->mc_tables);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1433,6 +1623,7 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
         return FLUID_OK;
     }
     if (bytes) {
+        psort_reset(c);  // the caller's array is in slot order
         HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
         if (c->is_slab) {  // the caller passes the global array: keep what this slab owns
             const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
@@ -1467,7 +1658,16 @@ int fluid_download_buffer(fluid_ctx* c, int buffer_id, void* host, uint64_t byte
         return FLUID_OK;
     }
     if (bytes) {
-        HIP_TRY(c, hipMemcpyAsync(host, c->particles(), bytes, hipMemcpyDeviceToHost, c->stream));
+        const float4* src = c->particles();
+        if (c->ps.valid) {  // stored sorted by bin: slot order into the buffer that is free between two sorts
+            float4* tmp = c->ps.cur ? c->particles_home() : c->ps.alt;
+            hipLaunchKernelGGL(k_pbin_to_slot_order, dim3((unsigned)((c->particle_capacity + 255) / 256)),
+                               dim3(256), 0, c->stream, src, c->ps.slot_of[c->ps.cur], c->particle_capacity,
+                               tmp);
+            HIP_TRY(c, hipGetLastError());
+            src = tmp;
+        }
+        HIP_TRY(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return FLUID_OK;
@@ -2194,6 +2394,18 @@ int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
             }
             *value = v;
+            return FLUID_OK;
+        }
+        case FLUID_STAT_PARTICLE_SORTS:
+            *value = c->ps.sorts;
+            return FLUID_OK;
+        case FLUID_STAT_PARTICLE_STRAYS: {
+            uint32_t v[2] = {0, 0};
+            if (c->ps.valid && c->ps.stray_count) {
+                HIP_TRY(c, hipMemcpyAsync(v, c->ps.stray_count, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+            *value = v[1];
             return FLUID_OK;
         }
         default:

@@ -1,0 +1,333 @@
+// kernels_particle_bins.h — particles kept sorted by "bin" (16 x 4 x 16 cells) on whole-grid contexts, and
+// the two particle passes of the step on that order.
+//
+// Why: 01_update_densities (update_densities.comp:29-36) is a scatter of one atomic per particle and
+// 14_particles (particles.comp:45-51) a gather of 24 taps per particle.  In slot order both go through
+// global memory: on a full 512^3 tank 01 is bound by cross-XCD atomics (two per cell) and 14 by the texture
+// addresser.  Particle order enters no result — the counts are integer sums, every particle is advected on
+// its own — so the engine is free to store the particles in any order as long as it remembers which slot
+// each one belongs to (`slot_of`): uploads, downloads and 00_init_particles speak slot order, everything
+// in between runs on the sorted storage.  With all particles of a bin contiguous,
+//   * 01 is a histogram of the bin in LDS (ds_add) and one plain 4-byte store per cell — no global atomics;
+//   * 14 stages the bin's velocities + 1 halo cell in LDS once and serves the 24 taps of each of its
+//     particles (about 8 k in water) from there.
+// Particles move, so between two sorts a bin's segment also holds "strays" that have left the bin: 01
+// lists them and a second small kernel adds them with global atomics (after the plain stores: stream
+// order), 14 takes the taps of a sample that leaves the tile from global memory, exactly as
+// k07_advect_tiled does.  The engine sorts again when the strays exceed a few per cent.
+//
+// The sort is a counting sort over bins in two passes of the particle buffer (histogram; scatter), each
+// block aggregating its 4096 particles per bin in an LDS table first so that sorted or spawn-ordered input
+// costs a handful of global atomics per block.  The order inside a bin is whatever the atomics gave: it
+// does not matter to the kernels above, and the slot of every particle travels with it.
+#pragma once
+
+#include "kernels_sampler.h"
+
+namespace fluid {
+
+constexpr int PBIN_X = 16, PBIN_Y = 4, PBIN_Z = 16;  // divides the activity brick (256 x 4 x 16)
+constexpr int PBIN_CELLS = PBIN_X * PBIN_Y * PBIN_Z;
+static_assert(BRICK_X % PBIN_X == 0 && BRICK_Y == PBIN_Y && BRICK_Z == PBIN_Z, "a bin lies in one brick");
+
+struct PBinK {
+    int nx, ny, nz;
+    uint32_t bins;  // nx * ny * nz; key `bins` = "counts nowhere" (inactive, outside the grid, NaN)
+};
+
+// the bin a particle counts in: the cell of update_densities.comp:35 (ivec3 truncation; dropped outside)
+__device__ __forceinline__ bool particle_cell(const float4& q, const GridK& g, const ParamsK& p, int& cx,
+                                              int& cy, int& cz) {
+    return q.w == p.active_w && trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) &&
+           trunc_index(q.z, g.Dg, cz);
+}
+__device__ __forceinline__ uint32_t particle_bin(const float4& q, const GridK& g, const ParamsK& p,
+                                                 const PBinK& b) {
+    int cx, cy, cz;
+    if (!particle_cell(q, g, p, cx, cy, cz)) return b.bins;
+    return (uint32_t)(cx / PBIN_X + b.nx * (cy / PBIN_Y + b.ny * (cz / PBIN_Z)));
+}
+
+// ---- counting sort ------------------------------------------------------------------------------------
+constexpr int PSORT_THREADS = 256, PSORT_PER_THREAD = 16, PSORT_TABLE = 4096;
+constexpr uint32_t PSORT_EMPTY = 0xFFFFFFFFu;
+
+// insert `key` into the block's LDS table; returns the entry, or -1 when the table is crowded
+__device__ __forceinline__ int psort_insert(uint32_t* keys, uint32_t key) {
+    uint32_t h = (key * 2654435761u) >> 20;
+    for (int probe = 0; probe < 32; probe++) {
+        const uint32_t old = atomicCAS(&keys[h], PSORT_EMPTY, key);
+        if (old == PSORT_EMPTY || old == key) return (int)h;
+        h = (h + 1) & (PSORT_TABLE - 1);
+    }
+    return -1;
+}
+
+// pass 1: particles per bin
+__global__ void __launch_bounds__(PSORT_THREADS)
+k_pbin_histogram(const float4* __restrict__ particles, uint64_t capacity, GridK g, ParamsK p, PBinK b,
+                 uint32_t* __restrict__ bin_count) {
+    __shared__ uint32_t keys[PSORT_TABLE];
+    __shared__ uint32_t counts[PSORT_TABLE];
+    for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS) {
+        keys[i] = PSORT_EMPTY;
+        counts[i] = 0u;
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (PSORT_THREADS * PSORT_PER_THREAD);
+#pragma unroll 4
+    for (int k = 0; k < PSORT_PER_THREAD; k++) {
+        const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
+        if (i >= capacity) break;
+        const uint32_t key = particle_bin(particles[i], g, p, b);
+        const int e = psort_insert(keys, key);
+        if (e >= 0)
+            atomicAdd(&counts[e], 1u);
+        else
+            atomicAdd(&bin_count[key], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS)
+        if (keys[i] != PSORT_EMPTY) atomicAdd(&bin_count[keys[i]], counts[i]);
+}
+
+// exclusive prefix sum of bin_count[0 .. n) -> bin_start[0 .. n] and the scatter cursors (one workgroup:
+// n is a few hundred thousand at most)
+__global__ void __launch_bounds__(1024)
+k_pbin_scan(const uint32_t* __restrict__ bin_count, uint32_t n, uint32_t* __restrict__ bin_start,
+            uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += bin_count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele, inclusive
+        const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        bin_start[i] = run;
+        cursor[i] = run;
+        run += bin_count[i];
+    }
+    if (threadIdx.x == 1023) bin_start[n] = part[1023];
+}
+
+// pass 2: every particle to its bin's segment of `out`, its slot with it.  slot_in == nullptr: the input
+// is in slot order.
+__global__ void __launch_bounds__(PSORT_THREADS)
+k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict__ slot_in, uint64_t capacity,
+               GridK g, ParamsK p, PBinK b, uint32_t* __restrict__ cursor, float4* __restrict__ out,
+               uint32_t* __restrict__ slot_out) {
+    __shared__ uint32_t keys[PSORT_TABLE];
+    __shared__ uint32_t counts[PSORT_TABLE];  // particles of the block per entry, then the entry's base
+    for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS) {
+        keys[i] = PSORT_EMPTY;
+        counts[i] = 0u;
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (PSORT_THREADS * PSORT_PER_THREAD);
+    float4 q[PSORT_PER_THREAD];
+    int entry[PSORT_PER_THREAD];      // table entry, or -1: `rank` is the final position already
+    uint32_t rank[PSORT_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PSORT_PER_THREAD; k++) {
+        const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
+        entry[k] = -2;
+        if (i >= capacity) continue;
+        q[k] = particles[i];
+        const uint32_t key = particle_bin(q[k], g, p, b);
+        entry[k] = psort_insert(keys, key);
+        rank[k] = entry[k] >= 0 ? atomicAdd(&counts[entry[k]], 1u) : atomicAdd(&cursor[key], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS)
+        if (keys[i] != PSORT_EMPTY) counts[i] = atomicAdd(&cursor[keys[i]], counts[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PSORT_PER_THREAD; k++) {
+        if (entry[k] == -2) continue;
+        const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
+        const uint32_t dst = entry[k] >= 0 ? counts[entry[k]] + rank[k] : rank[k];
+        out[dst] = q[k];
+        slot_out[dst] = slot_in ? slot_in[i] : (uint32_t)i;
+    }
+}
+
+// sorted storage -> slot order (downloads)
+__global__ void k_pbin_to_slot_order(const float4* __restrict__ sorted, const uint32_t* __restrict__ slot_of,
+                                     uint64_t capacity, float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < capacity) out[slot_of[i]] = sorted[i];
+}
+
+// ---- 01_update_densities on sorted particles ----------------------------------------------------------
+// One workgroup per bin segment (grid-stride).  In-bin particles: LDS histogram, then one 4-byte store per
+// cell that counted something (ADD: an atomic add instead — the image was not cleared just before, so what
+// it holds has to stay, update_densities.comp:35 adds).  Strays (and the whole last segment, whose
+// particles counted nowhere when they were sorted): cell index appended to `strays`, added by
+// k01_binned_strays behind this kernel.  stray_count[0] = entries, [1] = particles found outside their bin.
+template <bool ADD>
+__global__ void __launch_bounds__(256)
+k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bin_start, PBinK b,
+           uint32_t* __restrict__ dens, GridK g, ParamsK p, uint8_t* __restrict__ particle_bricks, BrickK bk,
+           uint32_t* __restrict__ strays, uint32_t* __restrict__ stray_count) {
+    __shared__ uint32_t hist[PBIN_CELLS];
+    __shared__ int any;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (uint32_t bin = blockIdx.x; bin <= b.bins; bin += gridDim.x) {
+        const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
+        if (s == e) continue;  // workgroup-uniform
+        const bool real = bin < b.bins;
+        const int bx = (int)(bin % (uint32_t)b.nx), byz = (int)(bin / (uint32_t)b.nx);
+        const int x0 = bx * PBIN_X, y0 = (byz % b.ny) * PBIN_Y, z0 = (byz / b.ny) * PBIN_Z;
+        for (int i = threadIdx.x; i < PBIN_CELLS; i += 256) hist[i] = 0u;
+        if (threadIdx.x == 0) any = 0;
+        __syncthreads();
+        for (uint32_t i0 = s; i0 < e; i0 += 256) {
+            const uint32_t i = i0 + threadIdx.x;
+            bool stray = false;
+            uint32_t key = 0;
+            if (i < e) {
+                const float4 q = particles[i];
+                int cx, cy, cz;
+                if (particle_cell(q, g, p, cx, cy, cz)) {
+                    const int lx = cx - x0, ly = cy - y0, lz = cz - z0;
+                    if (real && (unsigned)lx < (unsigned)PBIN_X && (unsigned)ly < (unsigned)PBIN_Y &&
+                        (unsigned)lz < (unsigned)PBIN_Z) {
+                        atomicAdd(&hist[lx + PBIN_X * (ly + PBIN_Y * lz)], 1u);
+                    } else {
+                        stray = true;
+                        key = (uint32_t)cidx(g, cx, cy, cz);
+                    }
+                }
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(stray);
+            if (m) {  // one counter update per wavefront
+                uint32_t at = 0;
+                if (lane == __builtin_ctzll(m)) {
+                    at = atomicAdd(&stray_count[0], (uint32_t)__builtin_popcountll(m));
+                    if (real) atomicAdd(&stray_count[1], (uint32_t)__builtin_popcountll(m));
+                }
+                at = (uint32_t)__shfl((int)at, __builtin_ctzll(m), 64);
+                if (stray) strays[at + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+        __syncthreads();
+        if (real) {
+            bool mine = false;
+            for (int c = threadIdx.x; c < PBIN_CELLS; c += 256) {
+                const uint32_t n = hist[c];
+                if (n == 0u) continue;
+                const int x = x0 + (c % PBIN_X), y = y0 + (c / PBIN_X) % PBIN_Y, z = z0 + c / (PBIN_X * PBIN_Y);
+                if (ADD)
+                    atomicAdd(&dens[cidx(g, x, y, z)], n);
+                else
+                    dens[cidx(g, x, y, z)] = n;
+                mine = true;
+            }
+            if (mine) any = 1;
+            __syncthreads();
+            if (threadIdx.x == 0 && any && particle_bricks)
+                particle_bricks[brick_index(bk, x0 / BRICK_X, y0 / BRICK_Y, z0 / BRICK_Z)] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k01_binned_strays(const uint32_t* __restrict__ strays, const uint32_t* __restrict__ stray_count,
+                  uint32_t* __restrict__ dens, GridK g, uint8_t* __restrict__ particle_bricks, BrickK bk) {
+    const uint32_t n = stray_count[0];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t key = strays[i];
+        atomicAdd(&dens[key], 1u);
+        if (particle_bricks) {
+            const int x = (int)(key % (uint32_t)g.W), yz = (int)(key / (uint32_t)g.W);
+            particle_bricks[brick_index(bk, x / BRICK_X, (yz % g.H) / BRICK_Y, (yz / g.H) / BRICK_Z)] = 1;
+        }
+    }
+}
+
+// ---- 14_particles on sorted particles -----------------------------------------------------------------
+// Velocity tile of a bin: its cells and one cell around them (a particle in cell c takes its taps from
+// c-1 .. c+1, axis_taps), one array per component.  Cells outside the image are never addressed: taps are
+// clamped into the image before the lookup.
+constexpr int PTILE_W = PBIN_X + 2, PTILE_H = PBIN_Y + 2, PTILE_D = PBIN_Z + 2;
+constexpr int PTILE_CELLS = PTILE_W * PTILE_H * PTILE_D;
+struct BinTile {
+    static constexpr bool enabled = true;
+    static constexpr int W = PTILE_W, H = PTILE_H;
+    const FLUID_LDS_F float* comp[3];
+    int x_org, y_org, z_org;
+    __device__ __forceinline__ int slot(int z) const {
+        const int d = z - z_org;
+        return (unsigned)d < (unsigned)PTILE_D ? d : -1;
+    }
+};
+
+__global__ void __launch_bounds__(256)
+k14_binned(const float4* __restrict__ v1, float4* __restrict__ particles,
+           const uint32_t* __restrict__ bin_start, PBinK b, GridK g, ParamsK p,
+           uint32_t* __restrict__ violation) {
+    __shared__ float tile[3][PTILE_CELLS];
+    const Axes axes = make_axes(g);
+    for (uint32_t bin = blockIdx.x; bin <= b.bins; bin += gridDim.x) {
+        const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
+        if (s == e) continue;  // workgroup-uniform
+        if (bin == b.bins) {   // counted nowhere when sorted: wherever they are now, the taps come from memory
+            for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
+                float4 q = particles[i];
+                if (q.w == p.active_w) {
+                    const float vx = sample_comp<0>(v1, g, axes, q.x, q.y, q.z, violation);
+                    const float vy = sample_comp<1>(v1, g, axes, q.x, q.y, q.z, violation);
+                    const float vz = sample_comp<2>(v1, g, axes, q.x, q.y, q.z, violation);
+                    q.x = q.x + vx * p.dt;
+                    q.y = q.y + vy * p.dt;
+                    q.z = q.z + vz * p.dt;
+                    particles[i] = q;
+                }
+            }
+            continue;
+        }
+        const int bx = (int)(bin % (uint32_t)b.nx), byz = (int)(bin / (uint32_t)b.nx);
+        BinTile t;
+        t.x_org = bx * PBIN_X - 1;
+        t.y_org = (byz % b.ny) * PBIN_Y - 1;
+        t.z_org = (byz / b.ny) * PBIN_Z - 1;
+        __syncthreads();  // the previous bin's taps are done with the tile
+        for (int c = threadIdx.x; c < PTILE_CELLS; c += 256) {
+            const int x = t.x_org + c % PTILE_W, y = t.y_org + (c / PTILE_W) % PTILE_H,
+                      z = t.z_org + c / (PTILE_W * PTILE_H);
+            if ((unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H && (unsigned)z < (unsigned)g.Dl) {
+                const float4 v = v1[cidx(g, x, y, z)];
+                tile[0][c] = v.x;
+                tile[1][c] = v.y;
+                tile[2][c] = v.z;
+            }
+        }
+        __syncthreads();
+        t.comp[0] = (const FLUID_LDS_F float*)tile[0];
+        t.comp[1] = (const FLUID_LDS_F float*)tile[1];
+        t.comp[2] = (const FLUID_LDS_F float*)tile[2];
+        for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
+            float4 q = particles[i];
+            if (q.w == p.active_w) {  // particles.comp:48
+                const float vx = sample_comp<0, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
+                const float vy = sample_comp<1, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
+                const float vz = sample_comp<2, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
+                q.x = q.x + vx * p.dt;  // :50
+                q.y = q.y + vy * p.dt;
+                q.z = q.z + vz * p.dt;
+                particles[i] = q;
+            }
+        }
+    }
+}
+
+}  // namespace fluid

@@ -81,6 +81,7 @@ struct NoTile {
 };
 struct VelTile {
     static constexpr bool enabled = true;
+    static constexpr int W = TILE_W, H = TILE_H;  // row length and rows per plane of comp[]
     const FLUID_LDS_F float* comp[3];
     int x_org, y_org, z_lo, z_rot;
     // ring slot of local plane z, or -1 when the plane is not in the window
@@ -124,13 +125,13 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
     if constexpr (Tile::enabled) {
         const int tx0 = x0 - tile.x_org, tx1 = x1 - tile.x_org, ty0 = y0 - tile.y_org,
                   ty1 = y1 - tile.y_org, tz0 = tile.slot(z0), tz1 = tile.slot(z1);
-        from_tile = (unsigned)tx0 < (unsigned)TILE_W && (unsigned)tx1 < (unsigned)TILE_W &&
-                    (unsigned)ty0 < (unsigned)TILE_H && (unsigned)ty1 < (unsigned)TILE_H && tz0 >= 0 &&
-                    tz1 >= 0;
+        constexpr int TW = Tile::W, TH = Tile::H;
+        from_tile = (unsigned)tx0 < (unsigned)TW && (unsigned)tx1 < (unsigned)TW &&
+                    (unsigned)ty0 < (unsigned)TH && (unsigned)ty1 < (unsigned)TH && tz0 >= 0 && tz1 >= 0;
         if (from_tile) {
             const FLUID_LDS_F float* t = tile.comp[COMP];
-            const int r00 = TILE_W * (ty0 + TILE_H * tz0), r10 = TILE_W * (ty1 + TILE_H * tz0);
-            const int r01 = TILE_W * (ty0 + TILE_H * tz1), r11 = TILE_W * (ty1 + TILE_H * tz1);
+            const int r00 = TW * (ty0 + TH * tz0), r10 = TW * (ty1 + TH * tz0);
+            const int r01 = TW * (ty0 + TH * tz1), r11 = TW * (ty1 + TH * tz1);
             c000 = t[r00 + tx0]; c100 = t[r00 + tx1];
             c010 = t[r10 + tx0]; c110 = t[r10 + tx1];
             c001 = t[r01 + tx0]; c101 = t[r01 + tx1];
