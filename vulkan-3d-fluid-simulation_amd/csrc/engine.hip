@@ -92,7 +92,7 @@ struct fluid_ctx {
         bool valid = false;   // ... sorted, slot_of[cur] and bin_start describe it
         bool failed = false;  // an allocation failed: slot order from now on
         uint64_t sorts = 0;
-        uint32_t last_strays = 0;
+        double stray_steps = 0.0;  // sum over the steps since the last sort of the fraction of strays
     } ps;
     bool dens_zero = false;  // PARTICLE_DENSITIES was cleared and nothing has counted into it since
     uint32_t pressure_iterations = 200;
@@ -845,7 +845,7 @@ void psort_reset(fluid_ctx* c) {
     c->ps.valid = false;
     c->ps.cur = 0;
     c->ps.stray_pending = false;
-    c->ps.last_strays = 0;
+    c->ps.stray_steps = 0.0;
 }
 bool psort_alloc(fluid_ctx* c) {
     auto& ps = c->ps;
@@ -899,11 +899,15 @@ int psort_sort(fluid_ctx* c) {
     ps.valid = true;
     ps.sorts++;
     ps.stray_pending = false;
-    ps.last_strays = 0;
+    ps.stray_steps = 0.0;
     return FLUID_OK;
 }
-// before 01_update_densities: sort if the storage is not sorted yet, or if the last 01 found too many
-// particles outside their bins (read one step late, without waiting for it)
+// Before 01_update_densities: sort if the storage is not sorted yet, or when the strays have cost as much
+// as a sort would.  A stray costs 01 a global atomic and 14 its taps from global memory, about 70 ps; a sort
+// about 21 ps per slot (two passes over the buffer; measured with 1 G particles): so the storage is sorted
+// again once the fractions of strays of the steps since the last sort add up to 0.3 — with strays growing
+// linearly that is the interval that minimises sort + stray time.  The count of the last 01 is read one step
+// late, without waiting for it.
 int psort_before_count(fluid_ctx* c) {
     auto& ps = c->ps;
     if (!psort_wanted(c) || !psort_alloc(c)) {
@@ -921,11 +925,11 @@ int psort_before_count(fluid_ctx* c) {
         return FLUID_OK;
     }
     if (ps.stray_pending && hipEventQuery(ps.stray_ev) == hipSuccess) {
-        ps.last_strays = ps.stray_host[1];
+        ps.stray_steps += (double)ps.stray_host[1] / (double)c->particle_capacity;
         ps.stray_pending = false;
     }
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
-    const bool again = mode == 3 || (mode != 4 && (uint64_t)ps.last_strays * 16 > c->particle_capacity);
+    const bool again = mode == 3 || (mode != 4 && ps.stray_steps >= 0.3);
     if (!ps.valid || again) return psort_sort(c);
     return FLUID_OK;
 }
@@ -1228,9 +1232,13 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_14_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
             if (c->ps.valid) {
-                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)c->ps.bk.bins + 1, 256 * 64);
+                // few full bins (a sparse scene): two workgroups share a bin, each staging its tile (512^3 dam
+                // break: 0.36 -> 0.26 ms; the full tank loses 8 % that way)
+                const uint32_t parts = c->particle_capacity / (8u * PBIN_CELLS) < 256 * 32 ? 2u : 1u;
+                const unsigned blocks =
+                    (unsigned)std::min<uint64_t>(((uint64_t)c->ps.bk.bins + 1) * parts, 256 * 64);
                 hipLaunchKernelGGL(k14_binned, dim3(blocks), dim3(256), 0, c->stream, V1, c->particles(),
-                                   c->ps.bin_start, c->ps.bk, g, pk, c->flags());
+                                   c->ps.bin_start, c->ps.bk, g, pk, c->flags(), parts);
             } else {
                 hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
                                    c->particles(), c->particle_capacity, g, pk, c->flags());

@@ -271,15 +271,61 @@ struct BinTile {
     }
 };
 
+// The three samples of particles.comp:46-47 at one position, taps from the bin's tile.  Same arithmetic
+// as three sample_comp calls (axis_taps per axis and stagger, the lerps in the same order), organised
+// around what they share: along each axis the component staggered on it uses one pair of taps and the other
+// two use another, so there are six axis_taps instead of nine and ONE in-tile test for all 24 taps (the
+// unstaggered pair starts lowest, the staggered pair ends highest: axis_taps is monotonic).  Returns false
+// — nothing sampled — when a tap lies outside the tile.
+__device__ __forceinline__ bool tile_velocity(const BinTile& t, const GridK& g, const Axes& axes, float px,
+                                              float py, float pz, float& vx, float& vy, float& vz) {
+    int x0s, x1s, x0c, x1c, y0s, y1s, y0c, y1c, z0s, z1s, z0c, z1c;
+    float axs, axc, ays, ayc, azs, azc;
+    axis_taps(px + 0.5f, axes.x, x0s, x1s, axs);
+    axis_taps(px + 0.0f, axes.x, x0c, x1c, axc);
+    axis_taps(py + 0.5f, axes.y, y0s, y1s, ays);
+    axis_taps(py + 0.0f, axes.y, y0c, y1c, ayc);
+    axis_taps(pz + 0.5f, axes.z, z0s, z1s, azs);
+    axis_taps(pz + 0.0f, axes.z, z0c, z1c, azc);
+    const int xo = t.x_org, yo = t.y_org, zo = t.z_org + g.z0;  // z taps are global planes
+    if (!((unsigned)(x0c - xo) < (unsigned)PTILE_W && (unsigned)(x1s - xo) < (unsigned)PTILE_W &&
+          (unsigned)(y0c - yo) < (unsigned)PTILE_H && (unsigned)(y1s - yo) < (unsigned)PTILE_H &&
+          (unsigned)(z0c - zo) < (unsigned)PTILE_D && (unsigned)(z1s - zo) < (unsigned)PTILE_D))
+        return false;
+    auto tri = [&](const FLUID_LDS_F float* c, int x0, int x1, float ax, int y0, int y1, float ay, int z0,
+                   int z1, float az) {
+        const int r00 = PTILE_W * ((y0 - yo) + PTILE_H * (z0 - zo)) - xo;
+        const int r10 = PTILE_W * ((y1 - yo) + PTILE_H * (z0 - zo)) - xo;
+        const int r01 = PTILE_W * ((y0 - yo) + PTILE_H * (z1 - zo)) - xo;
+        const int r11 = PTILE_W * ((y1 - yo) + PTILE_H * (z1 - zo)) - xo;
+        const float c00 = lerp1(c[r00 + x0], c[r00 + x1], ax), c10 = lerp1(c[r10 + x0], c[r10 + x1], ax);
+        const float c01 = lerp1(c[r01 + x0], c[r01 + x1], ax), c11 = lerp1(c[r11 + x0], c[r11 + x1], ax);
+        return lerp1(lerp1(c00, c10, ay), lerp1(c01, c11, ay), az);
+    };
+    vx = tri(t.comp[0], x0s, x1s, axs, y0c, y1c, ayc, z0c, z1c, azc);
+    vy = tri(t.comp[1], x0c, x1c, axc, y0s, y1s, ays, z0c, z1c, azc);
+    vz = tri(t.comp[2], x0c, x1c, axc, y0c, y1c, ayc, z0s, z1s, azs);
+    return true;
+}
+
+// One workgroup per bin segment (grid-stride), or per `parts`-th of one when there are few full bins.
 __global__ void __launch_bounds__(256)
 k14_binned(const float4* __restrict__ v1, float4* __restrict__ particles,
            const uint32_t* __restrict__ bin_start, PBinK b, GridK g, ParamsK p,
-           uint32_t* __restrict__ violation) {
+           uint32_t* __restrict__ violation, uint32_t parts) {
     __shared__ float tile[3][PTILE_CELLS];
     const Axes axes = make_axes(g);
-    for (uint32_t bin = blockIdx.x; bin <= b.bins; bin += gridDim.x) {
-        const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
+    const uint32_t work = (b.bins + 1u) * parts;
+    for (uint32_t w = blockIdx.x; w < work; w += gridDim.x) {
+        const uint32_t bin = w / parts, part = w - bin * parts;
+        uint32_t s = bin_start[bin], e = bin_start[bin + 1];
         if (s == e) continue;  // workgroup-uniform
+        if (parts > 1u) {
+            const uint32_t len = (e - s + parts - 1u) / parts;
+            s = min(e, s + part * len);
+            e = min(e, s + len);
+            if (s == e) continue;
+        }
         if (bin == b.bins) {   // counted nowhere when sorted: wherever they are now, the taps come from memory
             for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
                 float4 q = particles[i];
@@ -318,9 +364,12 @@ k14_binned(const float4* __restrict__ v1, float4* __restrict__ particles,
         for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
             float4 q = particles[i];
             if (q.w == p.active_w) {  // particles.comp:48
-                const float vx = sample_comp<0, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
-                const float vy = sample_comp<1, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
-                const float vz = sample_comp<2, BinTile>(v1, g, axes, q.x, q.y, q.z, violation, t);
+                float vx, vy, vz;
+                if (!tile_velocity(t, g, axes, q.x, q.y, q.z, vx, vy, vz)) {  // a stray
+                    vx = sample_comp<0>(v1, g, axes, q.x, q.y, q.z, violation);
+                    vy = sample_comp<1>(v1, g, axes, q.x, q.y, q.z, violation);
+                    vz = sample_comp<2>(v1, g, axes, q.x, q.y, q.z, violation);
+                }
                 q.x = q.x + vx * p.dt;  // :50
                 q.y = q.y + vy * p.dt;
                 q.z = q.z + vz * p.dt;
