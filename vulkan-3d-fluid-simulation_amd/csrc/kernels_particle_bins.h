@@ -275,36 +275,65 @@ struct BinTile {
 // as three sample_comp calls (axis_taps per axis and stagger, the lerps in the same order), organised
 // around what they share: along each axis the component staggered on it uses one pair of taps and the other
 // two use another, so there are six axis_taps instead of nine and ONE in-tile test for all 24 taps (the
-// unstaggered pair starts lowest, the staggered pair ends highest: axis_taps is monotonic).  Returns false
-// — nothing sampled — when a tap lies outside the tile.
+// unstaggered pair starts lowest, the staggered pair ends highest: axis_taps is monotonic).  The kernel is
+// bound by VALU issue (counters: 93 % busy), so independent fp32 operations of the same kind go in pairs
+// through the packed instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue, each rounded
+// like its scalar form; no contraction): both staggers of an axis, both x-lerps of a row pair, both y-lerps.
+// Returns false — nothing sampled — when a tap lies outside the tile.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 lerp2(pk2 A, pk2 B, pk2 a) { return ((pk2)(1.0f) - a) * A + a * B; }
+// axis_taps for coord + 0.5f (.x) and coord + 0.0f (.y) at once
+__device__ __forceinline__ void axis_taps2(float coord, const AxisN& ax, int (&i0)[2], int (&i1)[2], pk2& a) {
+    const pk2 c = (pk2)(coord) + (pk2){0.5f, 0.0f};
+    pk2 s;
+    if (ax.pow2)
+        s = c * (pk2)(ax.inv);
+    else
+        s = (pk2){c.x / ax.fn, c.y / ax.fn};
+    const pk2 u = s * (pk2)(ax.fn);
+    const pk2 ub = u - (pk2)(0.5f);
+    pk2 fl = (pk2){floorf(ub.x), floorf(ub.y)};
+    a = ub - fl;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float f = k == 0 ? fl.x : fl.y;
+        if (!(f >= -1.0f)) f = -1.0f;  // also catches NaN
+        if (f > ax.fn) f = ax.fn;
+        const int lo = (int)f, hi = lo + 1;
+        i0[k] = min(max(lo, 0), ax.n - 1);
+        i1[k] = min(max(hi, 0), ax.n - 1);
+    }
+}
 __device__ __forceinline__ bool tile_velocity(const BinTile& t, const GridK& g, const Axes& axes, float px,
                                               float py, float pz, float& vx, float& vy, float& vz) {
-    int x0s, x1s, x0c, x1c, y0s, y1s, y0c, y1c, z0s, z1s, z0c, z1c;
-    float axs, axc, ays, ayc, azs, azc;
-    axis_taps(px + 0.5f, axes.x, x0s, x1s, axs);
-    axis_taps(px + 0.0f, axes.x, x0c, x1c, axc);
-    axis_taps(py + 0.5f, axes.y, y0s, y1s, ays);
-    axis_taps(py + 0.0f, axes.y, y0c, y1c, ayc);
-    axis_taps(pz + 0.5f, axes.z, z0s, z1s, azs);
-    axis_taps(pz + 0.0f, axes.z, z0c, z1c, azc);
+    int x0[2], x1[2], y0[2], y1[2], z0[2], z1[2];  // [0] staggered (+0.5), [1] not
+    pk2 ax, ay, az;
+    axis_taps2(px, axes.x, x0, x1, ax);
+    axis_taps2(py, axes.y, y0, y1, ay);
+    axis_taps2(pz, axes.z, z0, z1, az);
     const int xo = t.x_org, yo = t.y_org, zo = t.z_org + g.z0;  // z taps are global planes
-    if (!((unsigned)(x0c - xo) < (unsigned)PTILE_W && (unsigned)(x1s - xo) < (unsigned)PTILE_W &&
-          (unsigned)(y0c - yo) < (unsigned)PTILE_H && (unsigned)(y1s - yo) < (unsigned)PTILE_H &&
-          (unsigned)(z0c - zo) < (unsigned)PTILE_D && (unsigned)(z1s - zo) < (unsigned)PTILE_D))
+    if (!((unsigned)(x0[1] - xo) < (unsigned)PTILE_W && (unsigned)(x1[0] - xo) < (unsigned)PTILE_W &&
+          (unsigned)(y0[1] - yo) < (unsigned)PTILE_H && (unsigned)(y1[0] - yo) < (unsigned)PTILE_H &&
+          (unsigned)(z0[1] - zo) < (unsigned)PTILE_D && (unsigned)(z1[0] - zo) < (unsigned)PTILE_D))
         return false;
-    auto tri = [&](const FLUID_LDS_F float* c, int x0, int x1, float ax, int y0, int y1, float ay, int z0,
-                   int z1, float az) {
-        const int r00 = PTILE_W * ((y0 - yo) + PTILE_H * (z0 - zo)) - xo;
-        const int r10 = PTILE_W * ((y1 - yo) + PTILE_H * (z0 - zo)) - xo;
-        const int r01 = PTILE_W * ((y0 - yo) + PTILE_H * (z1 - zo)) - xo;
-        const int r11 = PTILE_W * ((y1 - yo) + PTILE_H * (z1 - zo)) - xo;
-        const float c00 = lerp1(c[r00 + x0], c[r00 + x1], ax), c10 = lerp1(c[r10 + x0], c[r10 + x1], ax);
-        const float c01 = lerp1(c[r01 + x0], c[r01 + x1], ax), c11 = lerp1(c[r11 + x0], c[r11 + x1], ax);
-        return lerp1(lerp1(c00, c10, ay), lerp1(c01, c11, ay), az);
+    // component `c`, staggered on the axes whose s* flag is 0 ([0] = staggered taps)
+    auto tri = [&](const FLUID_LDS_F float* c, int sx, int sy, int sz) {
+        const int r00 = PTILE_W * ((y0[sy] - yo) + PTILE_H * (z0[sz] - zo)) - xo;
+        const int r10 = PTILE_W * ((y1[sy] - yo) + PTILE_H * (z0[sz] - zo)) - xo;
+        const int r01 = PTILE_W * ((y0[sy] - yo) + PTILE_H * (z1[sz] - zo)) - xo;
+        const int r11 = PTILE_W * ((y1[sy] - yo) + PTILE_H * (z1[sz] - zo)) - xo;
+        const float wx = sx ? ax.y : ax.x, wy = sy ? ay.y : ay.x;
+        const pk2 cz0 = lerp2((pk2){c[r00 + x0[sx]], c[r10 + x0[sx]]}, (pk2){c[r00 + x1[sx]], c[r10 + x1[sx]]},
+                              (pk2)(wx));  // c00, c10
+        const pk2 cz1 = lerp2((pk2){c[r01 + x0[sx]], c[r11 + x0[sx]]}, (pk2){c[r01 + x1[sx]], c[r11 + x1[sx]]},
+                              (pk2)(wx));  // c01, c11
+        return lerp2((pk2){cz0.x, cz1.x}, (pk2){cz0.y, cz1.y}, (pk2)(wy));  // c0, c1
     };
-    vx = tri(t.comp[0], x0s, x1s, axs, y0c, y1c, ayc, z0c, z1c, azc);
-    vy = tri(t.comp[1], x0c, x1c, axc, y0s, y1s, ays, z0c, z1c, azc);
-    vz = tri(t.comp[2], x0c, x1c, axc, y0c, y1c, ayc, z0s, z1s, azs);
+    const pk2 cx = tri(t.comp[0], 0, 1, 1), cy = tri(t.comp[1], 1, 0, 1), cz = tri(t.comp[2], 1, 1, 0);
+    const pk2 vxy = lerp2((pk2){cx.x, cy.x}, (pk2){cx.y, cy.y}, (pk2)(az.y));  // x and y: z not staggered
+    vx = vxy.x;
+    vy = vxy.y;
+    vz = lerp1(cz.x, cz.y, az.x);
     return true;
 }
 
