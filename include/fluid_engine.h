@@ -522,8 +522,12 @@ typedef enum fluid_option {
                                    /* (default); 1 = process every cell                             */
     FLUID_OPT_ADVECT_KERNEL = 4,   /* 07_advect: 0 = velocity sampler tiled into LDS (default), 1 = taps    */
                                    /* straight from global memory                                    */
-    FLUID_OPT_SURFACE_KERNEL = 5,  /* 18_diffuse_float_densities: 0 = z-marching kernel (default), 1 = four */
-                                   /* cells per thread, one plane per workgroup                         */
+    FLUID_OPT_SURFACE_KERNEL = 5,  /* 18_diffuse_float_densities: 0 = z-marching kernels (default): the loop */
+                                   /* section applies two dispatches per pass over HBM (a third float image */
+                                   /* of the detailed grid is allocated on first use), single dispatches one; */
+                                   /* 1 = four cells per thread, one plane per workgroup, one dispatch per     */
+                                   /* pass; 100 + R = as 0 with R = 8, 10, 12, 14 or 16 rows per workgroup     */
+                                   /* in the two-dispatch kernel (tuning; default 12)                          */
     FLUID_OPT_LAUNCH_BOX = 6,      /* pressure loop on a sparse scene: 0 = launches cover only the box / x  */
                                    /* window that holds the water, which costs ONE stream synchronisation  */
                                    /* per step (the host reads 28 bytes); 1 = full-grid launches, every    */

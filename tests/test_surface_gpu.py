@@ -89,6 +89,26 @@ def test_surface_diffuse_many_planes_and_partial_tiles():
         assert_surface_equal(eng, st, "z march: ")
 
 
+@pytest.mark.parametrize("steps", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("size,res", [((68, 5, 18), 4), ((63, 7, 3), 8), ((10, 8, 6), 4)])
+def test_surface_diffuse_loop_two_dispatches_per_pass(size, res, steps):
+    """The 18 loop runs two dispatches per pass over HBM (k18_pair): several x tiles of 248 cells (detailed
+    widths 272 and 504), y tiles of 6 rows, more than one z chunk, random SOLID cells (their stale values in
+    both float images feed their neighbours, diffuse_densities.comp:56), every loop count parity: FLOAT_1
+    must hold the newest even iterate, FLOAT_2 the newest odd one, exactly as N single dispatches leave them."""
+    st = surface_state(size, res, seed=sum(size) + steps, cap=100)
+    with engine_for(st) as eng:
+        if steps == 6:
+            eng.set_option(E.OPT_SURFACE_KERNEL, 108)   # 8 rows per workgroup instead of 12
+        eng.run_section_loop("18_diffuse_float_densities", steps)
+        st.diffuse_float_densities(steps)
+        assert_surface_equal(eng, st, f"{size} x{steps}: ")
+        # and again on what the first loop left (the third image holds an old iterate now)
+        eng.run_section_loop("18_diffuse_float_densities", 4)
+        st.diffuse_float_densities(4)
+        assert_surface_equal(eng, st, f"{size} x{steps} + 4: ")
+
+
 def test_full_step_with_surface_prep_matches_oracle():
     """fluid_run_init / fluid_run_step of a surface_prep context = the reference's complete section
     lists (fluid_flow_sections.h:139-154, 163-388) up to the renderer."""

@@ -113,6 +113,8 @@ struct fluid_ctx {
     uint32_t surface_steps = 4;
     uint32_t surface_dispatch_index = 0;  // loop counter of the 18_diffuse_float_densities section
     bool surface_fuse17 = false;          // inside fluid_run_step: 16 also writes what 17 would
+    float* blur_tmp = nullptr;            // third float image of the fused 18 loop (k18_pair), first use
+    bool blur_tmp_failed = false;
     uint32_t* mc_tables = nullptr;        // MARCHING_CUBES_COUNTS_BUF (256 words) + _EDGES_BUF (256 * 15)
     bool mc_loaded[2] = {false, false};
     template <typename T>
@@ -1505,6 +1507,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->wide) (void)hipFree(c->wide);
     psort_release(c);
+    if (c->blur_tmp) (void)hipFree(c->blur_tmp);
     if (c->mc_tables) (void)hipFree(c->mc_tables);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1893,7 +1896,67 @@ int fluid_run_section_loop(fluid_ctx* c, int section_id, uint32_t iterations) {
         // FlowLoopPushConstantSection(float_density_diffuse_steps, ...), fluid_flow_sections.h:376-388
         HIP_TRY(c, hipSetDevice(c->device));
         c->surface_dispatch_index = 0;
-        for (uint32_t k = 0; k < iterations; k++) {
+        if (!c->surface)
+            return c->fail(FLUID_ERR_UNSUPPORTED,
+                           "section %d is a surface-prep pass: create the context with "
+                           "fluid_create_info.surface_prep", section_id);
+        // Two dispatches per pass over HBM (k18_pair, kernels_surface.h).  The pairs alternate between
+        // FLOAT_1 and a third image, which the first use allocates (on failure: one dispatch at a time).
+        uint32_t k = 0;
+        if (iterations >= 2 && c->sk.W % 4 == 0 &&
+            (c->opt[FLUID_OPT_SURFACE_KERNEL] == 0 || c->opt[FLUID_OPT_SURFACE_KERNEL] >= 100) &&
+            !c->blur_tmp_failed) {
+            if (!c->blur_tmp) {
+                void* q = nullptr;
+                if (hipMalloc(&q, c->surf_cells * 4) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->blur_tmp_failed = true;
+                }
+                c->blur_tmp = static_cast<float*>(q);
+            }
+        }
+        const int64_t sopt = c->opt[FLUID_OPT_SURFACE_KERNEL];
+        if (iterations >= 2 && c->sk.W % 4 == 0 && (sopt == 0 || sopt >= 100) && c->blur_tmp) {
+            const SurfK& s = c->sk;
+            float* f1 = c->surf<float>(FLUID_IMG_PARTICLE_DENSITIES_FLOAT_1);
+            float* f2 = c->surf<float>(FLUID_IMG_PARTICLE_DENSITIES_FLOAT_2);
+            const uint8_t* T = c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES);
+            const int R = sopt >= 100 ? (int)(sopt - 100) : K18_PAIR_ROWS;
+            const int zchunk = 32;
+            const dim3 pgrid((s.W + 247) / 248, (s.H + R - 3) / (R - 2), (s.D + zchunk - 1) / zchunk);
+            float* cur = f1;  // the complete image of the newest even iterate
+            SectionTimer tm{c};
+            int rc = tm.begin(section_id);
+            if (rc) return rc;
+            for (; k + 2 <= iterations; k += 2) {
+                float* out = cur == f1 ? c->blur_tmp : f1;
+                const bool last = k + 2 == iterations;  // FLOAT_2 ends with the last odd iterate
+#define FLUID_PAIR(RR)                                                                                         \
+    if (last)                                                                                                  \
+        hipLaunchKernelGGL((k18_pair<RR, true>), pgrid, dim3(64, RR, 1), 0, c->stream, T, cur, f2, out, s,     \
+                           c->params.dens_diffuse_k, c->pk.t_solid, zchunk);                                   \
+    else                                                                                                       \
+        hipLaunchKernelGGL((k18_pair<RR, false>), pgrid, dim3(64, RR, 1), 0, c->stream, T, cur, f2, out, s,    \
+                           c->params.dens_diffuse_k, c->pk.t_solid, zchunk);
+                if (R == 8) { FLUID_PAIR(8) }
+                else if (R == 10) { FLUID_PAIR(10) }
+                else if (R == 12) { FLUID_PAIR(12) }
+                else if (R == 14) { FLUID_PAIR(14) }
+                else { FLUID_PAIR(16) }
+#undef FLUID_PAIR
+                cur = out;
+            }
+            rc = hipGetLastError() == hipSuccess ? FLUID_OK : c->fail(FLUID_ERR_HIP, "k18_pair launch failed");
+            if (rc == FLUID_OK && cur != f1)  // an odd number of pairs: the newest even iterate belongs in FLOAT_1
+                rc = hipMemcpyAsync(f1, cur, c->surf_cells * 4, hipMemcpyDeviceToDevice, c->stream) == hipSuccess
+                         ? FLUID_OK
+                         : c->fail(FLUID_ERR_HIP, "copy of the blurred image failed");
+            int rc2 = tm.end();
+            if (rc || rc2) return rc ? rc : rc2;
+            if (c->timing) c->sec_calls[section_id] += k - 1;  // count dispatches
+            c->surface_dispatch_index = k;
+        }
+        for (; k < iterations; k++) {
             int rc = timed_section(c, section_id);
             if (rc) return rc;
         }

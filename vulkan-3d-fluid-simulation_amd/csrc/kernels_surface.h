@@ -334,6 +334,139 @@ k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const floa
     }
 }
 
+// ---- two dispatches of 18 per pass over HBM ---------------------------------------------------------------
+// The loop ping-pongs FLOAT_1 -> FLOAT_2 -> FLOAT_1 ... (fluid_flow_sections.h:376-388), and a dispatch does
+// not write the cells of SOLID simulation cells: they keep what the image it writes held before, so as
+// neighbours they contribute stale values — FLOAT_2's own for the odd iterates, FLOAT_1's (what 17 stored,
+// never touched by the loop) for the even ones.  k18_pair applies dispatches 2j and 2j+1 in one z march:
+//   `src`  a complete image of iterate 2j (solid cells: FLOAT_1's),
+//   `mid`  FLOAT_2: read at solid cells (iterate 2j+1 there = its stale value); STORE_MID also writes iterate
+//          2j+1 to it (the loop's last pair: FLOAT_2 ends with the last odd iterate),
+//   `dst`  receives iterate 2j+2 at every cell (solid cells: src's value), i.e. is complete again.
+// src and dst must differ (other workgroups still read src), so the pairs alternate between FLOAT_1 and a
+// third image; iterate 2j+1 lives in registers and LDS only.
+// A workgroup of 64 x R threads holds 256 x R cells: every thread forms iterate 2j+1 for its four cells one
+// plane ahead (stage 1), the inner 62 x (R-2) threads form iterate 2j+2 (stage 2) — rows and float4 columns
+// overlap by two between neighbouring workgroups, iterate 2j+1 is recomputed there, never exchanged, so the
+// results are those of two dispatches.  z neighbours come from the thread's registers (three planes per
+// iterate), y / x neighbours from the planes both iterates publish in LDS (double-buffered, one barrier per
+// plane).  Cells outside the image are 0 in every iterate (imageLoad out of bounds).
+constexpr int K18_PAIR_ROWS = 12;
+template <int R, bool STORE_MID>
+__global__ void __launch_bounds__(64 * R)
+k18_pair(const uint8_t* __restrict__ types, const float* __restrict__ src, float* __restrict__ mid,
+         float* __restrict__ dst, SurfK s, float a, uint32_t t_solid, int zchunk) {
+    __shared__ __attribute__((aligned(16))) float tile_a[2][R + 2][K18_ROW_FLOATS];  // iterate 2j
+    __shared__ __attribute__((aligned(16))) float tile_s[2][R][K18_ROW_FLOATS];      // iterate 2j+1
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = (int)blockIdx.x * 248 - 4 + 4 * tx;
+    const int y = (int)blockIdx.y * (R - 2) - 1 + ty;
+    const bool valid = (unsigned)x < (unsigned)s.W && (unsigned)y < (unsigned)s.H;
+    const bool writer = valid && tx >= 1 && tx <= 62 && ty >= 1 && ty <= R - 2;
+    const int zb = (int)blockIdx.z * zchunk, ze = min(zb + zchunk, s.D);
+    const float k0 = 1.0f - 6.0f * a;
+    const int64_t rowoff = (int64_t)x + (int64_t)s.W * (int64_t)y;
+    auto plane_ld = [&](int z) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && (unsigned)z < (unsigned)s.D) v = *reinterpret_cast<const float4*>(src + rowoff + s.plane * z);
+        return v;
+    };
+    // halo rows of iterate 2j: the first / last thread row also loads the row below / above the workgroup's
+    const bool halo_row = ty == 0 || ty == R - 1;
+    const int yh = ty == 0 ? y - 1 : y + 1;
+    const bool halo_in = halo_row && (unsigned)x < (unsigned)s.W && (unsigned)yh < (unsigned)s.H;
+    const int64_t halo_off = (int64_t)x + (int64_t)s.W * (int64_t)(halo_in ? yh : 0);
+    const int cx0 = valid ? x / s.res : 0, rem0 = valid ? x - cx0 * s.res : 0, cy = valid ? y / s.res : 0;
+    // which of the thread's four cells lie in SOLID simulation cells of detailed plane z
+    auto solid_bits = [&](int z) {
+        uint32_t m = 0u;
+        if (valid && (unsigned)z < (unsigned)s.D) {
+            const int64_t trow = (int64_t)s.sW * ((int64_t)cy + (int64_t)s.sH * (int64_t)(z / s.res));
+            int cx = cx0, rem = rem0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((uint32_t)types[trow + cx] == t_solid) m |= 1u << i;
+                if (++rem == s.res) {
+                    rem = 0;
+                    cx++;
+                }
+            }
+        }
+        return m;
+    };
+    // one dispatch for the thread's four cells: centre c, z neighbours zm / zp, y / x neighbours from `row`
+    // (the thread's row of the published plane; rows are K18_ROW_FLOATS apart)
+    auto blur4 = [&](const float4& c, const float4& zm, const float4& zp, const float* row, uint32_t solid,
+                     const float4& at_solid) {
+        const float4 yp = *reinterpret_cast<const float4*>(row + K18_ROW_FLOATS);
+        const float4 ym = *reinterpret_cast<const float4*>(row - K18_ROW_FLOATS);
+        const float xl = row[-1], xr = row[4];
+        const float cc[4] = {c.x, c.y, c.z, c.w};
+        const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
+        const float a_zp[4] = {zp.x, zp.y, zp.z, zp.w}, a_zm[4] = {zm.x, zm.y, zm.z, zm.w};
+        float out[4] = {at_solid.x, at_solid.y, at_solid.z, at_solid.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (solid & (1u << i)) continue;
+            const float nxp = i == 3 ? xr : cc[i == 3 ? 3 : i + 1];
+            const float nxm = i == 0 ? xl : cc[i == 0 ? 0 : i - 1];
+            float sum = nxp + nxm;  // diffuse_densities.comp:58-60, left to right
+            sum = sum + a_yp[i];
+            sum = sum + a_ym[i];
+            sum = sum + a_zp[i];
+            sum = sum + a_zm[i];
+            const float t1 = k0 * cc[i];
+            const float t2 = a * sum;
+            out[i] = t1 + t2;
+        }
+        return make_float4(out[0], out[1], out[2], out[3]);
+    };
+    // Step k forms iterate 2j+1 of plane k+1 and (from k = zb on) iterate 2j+2 of plane k.
+    float4 a_m = plane_ld(zb - 2), a_c = plane_ld(zb - 1), a_p = plane_ld(zb);  // iterate 2j: planes k, k+1, k+2
+    float4 s_m = make_float4(0.f, 0.f, 0.f, 0.f), s_c = s_m;                    // iterate 2j+1: planes k-1, k
+    uint32_t solid_c = 0u;  // SOLID cells of plane k (what stage 1 found for it a step ago)
+    for (int k = zb - 2; k < ze; k++) {
+        const int buf = k & 1;
+        const float4 a_next = plane_ld(k + 3);
+        // publish iterate 2j of plane k+1 (with the halo rows) and iterate 2j+1 of plane k
+        float* row_a = &tile_a[buf][ty + 1][K18_PAD + 4 * tx];
+        *reinterpret_cast<float4*>(row_a) = a_c;
+        if (halo_row) {
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (halo_in && (unsigned)(k + 1) < (unsigned)s.D)
+                h = *reinterpret_cast<const float4*>(src + halo_off + s.plane * (k + 1));
+            *reinterpret_cast<float4*>(&tile_a[buf][ty == 0 ? 0 : R + 1][K18_PAD + 4 * tx]) = h;
+        }
+        float* row_s = &tile_s[buf][ty][K18_PAD + 4 * tx];
+        *reinterpret_cast<float4*>(row_s) = s_c;
+        __syncthreads();
+        // stage 1: plane k+1
+        float4 s_p = make_float4(0.f, 0.f, 0.f, 0.f);
+        // a simulation cell spans `res` detailed planes: the mask changes only where a new one begins
+        uint32_t solid_p = solid_c;
+        if (k == zb - 2 || (k + 1) % s.res == 0) solid_p = solid_bits(k + 1);
+        if (valid && (unsigned)(k + 1) < (unsigned)s.D) {
+            const uint32_t solid = solid_p;
+            float4 stale = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (solid) stale = *reinterpret_cast<const float4*>(mid + rowoff + s.plane * (k + 1));
+            s_p = blur4(a_c, a_m, a_p, row_a, solid, stale);
+            if (STORE_MID && writer && k + 1 >= zb && k + 1 < ze)
+                *reinterpret_cast<float4*>(mid + rowoff + s.plane * (k + 1)) = s_p;
+        }
+        // stage 2: plane k (rows 0 and R-1 and lanes 0 and 63 only feed their neighbours)
+        if (writer && k >= zb) {
+            const float4 o = blur4(s_c, s_m, s_p, row_s, solid_c, a_m);
+            *reinterpret_cast<float4*>(dst + rowoff + s.plane * k) = o;
+        }
+        a_m = a_c;
+        a_c = a_p;
+        a_p = a_next;
+        s_m = s_c;
+        s_c = s_p;
+        solid_c = solid_p;
+    }
+}
+
 // ---- 31_render_surface as a triangle list (offline visualisation) -------------------
 // What the reference's marching-cubes geometry shader emits (render_surface.vert:19-25, render_surface.geom:
 // 45-103), stored instead of rasterised: one thread per render cell ((W-1) x (H-1) x (D-1) cells of the
