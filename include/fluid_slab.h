@@ -168,6 +168,11 @@ int fluid_slab_attach_transport(fluid_slab* s, const fluid_slab_transport* trans
 /* world == 1 needs no transport.  A single-rank rehearsal of an interior rank's work (both neighbours
  * present, every received plane filled by a device copy of a plane being sent): */
 int fluid_slab_attach_loopback(fluid_slab* s, int has_lower, int has_upper);
+/* The same rehearsal through RCCL itself: a communicator of one, every plane range goes out with ncclSend and
+ * comes back with ncclRecv (to / from this rank, inside one group: the i-th receive gets the i-th send) on
+ * the streams a real run uses.  What one GPU can check of the wire: the library that gets loaded, the calls,
+ * their stream order around split passes.  Bit-identical to fluid_slab_attach_loopback. */
+int fluid_slab_attach_rccl_self(fluid_slab* s, int has_lower, int has_upper);
 
 /* ---- the frame loop ----------------------------------------------------------------------------------- */
 int fluid_slab_run_init(fluid_slab* s);

@@ -109,6 +109,7 @@ def test_rccl_communicator_of_one_and_loopback_rehearsal():
     from fluid_amd import engine as E
     from fluid_amd import scenes
     from fluid_amd import slab as S
+    from helpers import assert_bit_equal
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     p = fluid_amd.default_params(128, 64, 64, 0)
@@ -119,15 +120,30 @@ def test_rccl_communicator_of_one_and_loopback_rehearsal():
         one.pressure_step()
         whole = one.engine.download_image(E.PRESSURES_1)
         assert np.isfinite(whole).all() and one.stat(S.STAT_EXCHANGES) == 0
-    with S.SlabDriver(p, 2, 4, pressure_iterations=40, device=0, halo_depth=4) as mid:
-        mid.attach_loopback(True, True)
-        z0, n = mid.slab
-        assert (z0, n) == (32, 16)
-        mid.upload_image(E.CELL_TYPES, scenes.full_fluid_types((n, 64, 128), z0, 64))
-        mid.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((n, 64, 128), z_begin=z0))
-        mid.pressure_step()
-        mid.engine.sync()
-        assert mid.stat(S.STAT_OVERLAPPED) > 0 and mid.stat(S.STAT_EFFECTIVE_HALO) == 4
+    # The same rehearsal twice: received planes filled by device copies, and by ncclSend / ncclRecv to the
+    # rank itself through a communicator of one — the real calls on the real streams, split passes and the
+    # events around them included.  Same bytes in the same order: the iterates must be bit-identical, for
+    # every overlap schedule.
+    for overlap in (S.OVERLAP_NONE, S.OVERLAP_BEFORE, S.OVERLAP_BOTH):
+        got = {}
+        for wire in ("copies", "rccl"):
+            with S.SlabDriver(p, 2, 4, pressure_iterations=40, device=0, halo_depth=4, overlap=overlap) as mid:
+                if wire == "copies":
+                    mid.attach_loopback(True, True)
+                else:
+                    mid.attach_rccl_self(True, True)
+                z0, n = mid.slab
+                assert (z0, n) == (32, 16)
+                mid.upload_image(E.CELL_TYPES, scenes.full_fluid_types((n, 64, 128), z0, 64))
+                mid.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((n, 64, 128), z_begin=z0))
+                mid.pressure_step()
+                mid.engine.sync()
+                assert mid.stat(S.STAT_EFFECTIVE_HALO) == 4 and mid.stat(S.STAT_EXCHANGES) > 0
+                assert (mid.stat(S.STAT_OVERLAPPED) > 0) == (overlap != S.OVERLAP_NONE)
+                got[wire] = (mid.engine.download_image(E.PRESSURES_1), mid.engine.download_image(E.PRESSURES_2))
+        for a, b in zip(got["copies"], got["rccl"]):
+            assert np.isfinite(a).all()
+            assert_bit_equal(a, b, f"loopback by copies vs by RCCL, overlap {overlap}")
 
 
 def test_single_rank_slab_bench_path_runs():

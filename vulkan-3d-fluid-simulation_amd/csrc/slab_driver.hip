@@ -322,6 +322,7 @@ struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     uint32_t* scratch = nullptr;  // device words for the small reductions
     static constexpr uint32_t kScratchWords = 1024;
+    bool self_loop = false;       // fluid_slab_attach_rccl_self: a communicator of one, every peer is rank 0
     ~RcclTransport() override {
         if (scratch) (void)hipFree(scratch);
         if (comm && api) (void)api->CommDestroy(comm);
@@ -336,10 +337,11 @@ struct RcclTransport : Transport {
         ncclResult_t r = api->GroupStart();
         if (r != ncclSuccess) return fail(r, "ncclGroupStart");
         for (const Xfer& x : ops) {
+            const int peer = self_loop ? 0 : x.peer;
             if (x.flags & FLUID_XFER_SEND)
-                r = api->Send(x.ptr, x.bytes, ncclUint8, x.peer, comm, stream);
+                r = api->Send(x.ptr, x.bytes, ncclUint8, peer, comm, stream);
             else
-                r = api->Recv(x.ptr, x.bytes, ncclUint8, x.peer, comm, stream);
+                r = api->Recv(x.ptr, x.bytes, ncclUint8, peer, comm, stream);
             if (r != ncclSuccess) {
                 (void)api->GroupEnd();
                 return fail(r, (x.flags & FLUID_XFER_SEND) ? "ncclSend" : "ncclRecv");
@@ -385,15 +387,16 @@ struct CallbackTransport : Transport {
     }
 };
 
-// one process standing in for an interior rank: every receive is filled by a device copy of a plane range
-// being sent (same sizes), no communicator; reductions are the identity
+// one process standing in for an interior rank: the i-th receive is filled by a device copy of the i-th
+// plane range being sent (same sizes; the pairing a communicator of one gives ncclSend / ncclRecv to
+// oneself), no communicator; reductions are the identity
 struct LoopbackTransport : Transport {
     bool stream_ordered() const override { return true; }
     int exchange(const std::vector<Xfer>& ops, hipStream_t stream) override {
         std::vector<const Xfer*> sends, recvs;
         for (const Xfer& x : ops) ((x.flags & FLUID_XFER_SEND) ? sends : recvs).push_back(&x);
         for (size_t i = 0; i < recvs.size() && !sends.empty(); i++) {
-            const Xfer* src = sends[(i + 1) % sends.size()];
+            const Xfer* src = sends[i % sends.size()];
             hipError_t e = hipMemcpyAsync(recvs[i]->ptr, src->ptr, std::min(recvs[i]->bytes, src->bytes),
                                           hipMemcpyDeviceToDevice, stream);
             if (e != hipSuccess) {
@@ -1151,6 +1154,32 @@ int fluid_slab_attach_loopback(fluid_slab* s, int has_lower, int has_upper) {
     if (!s) return FLUID_ERR_INVALID_ARG;
     if (!s->be->on_device()) return s->fail(FLUID_ERR_UNSUPPORTED, "loopback copies device memory");
     s->tr.reset(new LoopbackTransport());
+    s->loopback = true;
+    s->lo = has_lower ? (int)s->rank : -1;
+    s->hi = has_upper ? (int)s->rank : -1;
+    s->plans.clear();
+    return FLUID_OK;
+}
+
+int fluid_slab_attach_rccl_self(fluid_slab* s, int has_lower, int has_upper) {
+    if (!s) return FLUID_ERR_INVALID_ARG;
+    if (!s->be->on_device())
+        return s->fail(FLUID_ERR_UNSUPPORTED, "RCCL moves device memory: this driver computes on the host");
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return s->fail(FLUID_ERR_UNSUPPORTED, why);
+    std::unique_ptr<RcclTransport> t(new RcclTransport());
+    t->api = api;
+    t->self_loop = true;
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r == ncclSuccess) r = api->CommInitRank(&t->comm, 1, id, 0);
+    if (r != ncclSuccess)
+        return s->fail(FLUID_ERR_HIP, std::string("communicator of one: ") + api->GetErrorString(r));
+    void* ptr = nullptr;
+    HIPS(s, hipMalloc(&ptr, 4ull * RcclTransport::kScratchWords));
+    t->scratch = static_cast<uint32_t*>(ptr);
+    s->tr = std::move(t);
     s->loopback = true;
     s->lo = has_lower ? (int)s->rank : -1;
     s->hi = has_upper ? (int)s->rank : -1;

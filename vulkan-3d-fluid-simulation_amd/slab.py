@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "fluid_slab_partition", "fluid_slab_create", "fluid_slab_create_custom", "fluid_slab_destroy",
     "fluid_slab_last_error", "fluid_slab_engine", "fluid_slab_get_slab", "fluid_slab_rccl_unique_id",
     "fluid_slab_attach_rccl", "fluid_slab_attach_transport", "fluid_slab_attach_loopback",
+    "fluid_slab_attach_rccl_self",
     "fluid_slab_run_init", "fluid_slab_run_step", "fluid_slab_pressure_step", "fluid_slab_solve",
     "fluid_slab_exchange_image", "fluid_slab_set_option", "fluid_slab_get_stat",
 ]
@@ -129,6 +130,7 @@ def _lib():
             "fluid_slab_attach_rccl": (C.c_int, [vp, vp]),
             "fluid_slab_attach_transport": (C.c_int, [vp, C.POINTER(TransportTable)]),
             "fluid_slab_attach_loopback": (C.c_int, [vp, C.c_int, C.c_int]),
+            "fluid_slab_attach_rccl_self": (C.c_int, [vp, C.c_int, C.c_int]),
             "fluid_slab_run_init": (C.c_int, [vp]),
             "fluid_slab_run_step": (C.c_int, [vp]),
             "fluid_slab_pressure_step": (C.c_int, [vp]),
@@ -485,6 +487,10 @@ class SlabDriver:
 
     def attach_loopback(self, has_lower: bool = True, has_upper: bool = True):
         self._check(self._lib.fluid_slab_attach_loopback(self._h, int(has_lower), int(has_upper)))
+
+    def attach_rccl_self(self, has_lower: bool = True, has_upper: bool = True):
+        """The loopback rehearsal with ncclSend / ncclRecv to this rank itself (communicator of one)."""
+        self._check(self._lib.fluid_slab_attach_rccl_self(self._h, int(has_lower), int(has_upper)))
 
     # -- the frame loop -------------------------------------------------------------------------------
     def run_init(self):
