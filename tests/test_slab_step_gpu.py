@@ -172,3 +172,38 @@ def test_fast_flow_widens_the_sampler_halo_and_never_fails(world, size, fast, ex
     assert int(stats[S.STAT_SAMPLER_RERUNS]) > 0
     assert (int(stats[S.STAT_SAMPLER_WIDE]) > 0) == expect_wide
     assert int(stats[S.STAT_MIGRATED]) > 0
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_whole_step_rehearsal_by_copies_and_through_rccl_are_identical(grouped):
+    """One interior rank of a 3-way run, both neighbours played by itself: the whole step's exchanges (ghost
+    planes of every image, activity-brick layers, the status reduction) once as device copies and once as
+    ncclSend / ncclRecv / ncclAllReduce on a communicator of one.  Every image and the particle buffer end
+    bit-identical: the RCCL calls move the same bytes in the same stream order."""
+    import fluid_amd  # noqa: F401
+    from fluid_amd import engine as E
+    from fluid_amd import slab as S
+    from helpers import assert_bit_equal
+
+    size, iters = (64, 24, 48), 12
+    params, cap = scene_params(size)
+    got = {}
+    for wire in ("copies", "rccl"):
+        with S.SlabDriver(params, 1, 3, particle_capacity=cap, pressure_iterations=iters, device=0,
+                          grouped=grouped) as drv:
+            (drv.attach_loopback if wire == "copies" else drv.attach_rccl_self)(True, True)
+            drv.run_init()
+            drv.run_step()
+            z0, n = drv.slab
+            drv.engine.upload_image(E.VELOCITIES_1, drift((n, size[1], size[0])))
+            for _ in range(4):
+                drv.run_step()
+            drv.engine.sync()
+            assert drv.stat(S.STAT_EXCHANGES) > 0
+            got[wire] = {img: drv.engine.download_image(img) for img in
+                         (E.VELOCITIES_1, E.CELL_TYPES, E.PRESSURES_1, E.PRESSURES_2, E.DIVERGENCES,
+                          E.PARTICLE_DENSITIES_IMG)}
+            got[wire]["particles"] = drv.engine.download_particles()
+    for k in got["copies"]:
+        assert_bit_equal(got["copies"][k], got["rccl"][k], f"whole step, copies vs RCCL, {k}")
+    assert np.isfinite(got["rccl"][E.PRESSURES_1]).all()
