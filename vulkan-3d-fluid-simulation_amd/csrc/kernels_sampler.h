@@ -289,6 +289,21 @@ __global__ void k07_advect(const uint8_t* __restrict__ t, const float4* __restri
 // loads.  Planes in which no cell of the column is advected (cell or +x/+y/+z neighbour WATER,
 // advect.comp:65-68) only copy.  Same arithmetic as k07_advect.
 constexpr int K07_ZM = 16;  // = BRICK_Z: a workgroup stays inside one brick (quiet_bricks.h)
+// Bitwise OR over the 256 threads of the workgroup with one barrier: three words of LDS in rotation (call n
+// ORs into word n mod 3 and clears word n+1 mod 3, which was last read before the barrier of call n-1).
+// (The device library's __ockl_wgred_or_i32 takes two barriers and 256 B of LDS.)
+struct WgOr {
+    uint32_t* words;
+    int n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t v) {
+        uint32_t* w = words + n % 3;
+        if (threadIdx.x == 0 && threadIdx.y == 0) words[(n + 1) % 3] = 0u;
+        if (v) atomicOr(w, v);
+        __syncthreads();
+        n++;
+        return *w;
+    }
+};
 template <bool FORCES>
 __global__ void __launch_bounds__(256)
 k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
@@ -333,6 +348,10 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
         }
     }
     __shared__ float tile_mem[3][TILE_CELLS];
+    __shared__ uint32_t or_words[3];
+    if (threadIdx.x == 0 && threadIdx.y == 0) or_words[0] = 0u;
+    __syncthreads();
+    WgOr wg_or{or_words, 0};
     const Axes axes = make_axes(g);
     const bool pow2_grid = axes.x.pow2 && axes.y.pow2 && axes.z.pow2;  // coord / n * n == coord everywhere
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -389,7 +408,7 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                       (uint32_t)t[cidx(g, x, y, lz + 1)] == p.t_water;
             }
             // the vote is also the barrier behind the previous plane's reads of the window
-            const bool any_adv = __ockl_wgred_or_i32(adv ? 1 : 0) != 0;
+            const bool any_adv = wg_or(adv ? 1u : 0u) != 0u;
             float4 o = cur;
             if (any_adv) {
                 const int need_lo = lz - TILE_HALO, need_hi = lz + TILE_HALO + 1;
@@ -404,7 +423,7 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                 have_lo = need_lo;
                 have_hi = need_hi;
                 // bitwise OR over the workgroup (and the barrier in front of the window's readers)
-                bad = (bad & ~staged) | (uint32_t)__ockl_wgred_or_i32((int)sp_bits);
+                bad = (bad & ~staged) | wg_or(sp_bits);
                 tile.z_lo = need_lo;
                 tile.z_rot = slot_of(need_lo);
                 // the face samples touch the planes lz-1, lz, lz+1
