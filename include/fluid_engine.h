@@ -580,7 +580,9 @@ typedef enum fluid_stat {
     FLUID_STAT_BRICKS = 0,       /* activity bricks of this context (256 x 4 x 16 cells each)          */
     FLUID_STAT_QUIET_BRICKS = 1, /* bricks the last fluid_run_step skipped in 07+08, 09+10+11 and 13   */
     FLUID_STAT_PARTICLE_SORTS = 2,   /* sorts of the particle storage so far (FLUID_OPT_PARTICLE_SORT)     */
-    FLUID_STAT_PARTICLE_STRAYS = 3   /* particles the last 01 found outside the bin they are stored in     */
+    FLUID_STAT_PARTICLE_STRAYS = 3,  /* particles the last 01 found outside the bin they are stored in     */
+    FLUID_STAT_PARTICLE_BINNED = 4   /* 1 while 01 and 14 run on bins; 0 in slot order or while the flow    */
+                                     /* moves the particles faster than sorting pays (tried again later)    */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 

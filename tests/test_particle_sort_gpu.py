@@ -67,10 +67,13 @@ def test_sorted_full_steps_match_oracle(mode):
         assert_state_equal(eng, st, ctx=f"mode {mode} switched off: ")
 
 
-def test_sorted_fast_drift_strays_and_resort():
-    """A blob carried 2-3 cells per step through a wide grid: most particles leave their bin between two
-    sorts (01 lists them, 14 takes their taps from global memory), and the engine sorts again on its own
-    once the strays pass a sixteenth of the slots."""
+@pytest.mark.parametrize("speed,steps", [(6.0, 24), (50.0, 10)])
+def test_sorted_drift_strays_resort_and_suspension(speed, steps):
+    """A blob carried through a wide grid.  At 0.3 cells per step particles trickle out of their bins (01
+    lists them, 14 takes their taps from global memory) and the engine sorts again when they have cost as
+    much as a sort; at 2.5 cells per step nearly all leave between two steps — sorting cannot pay, and the
+    engine returns the storage to slot order and its slot-order kernels (to try again 64 steps later).
+    Bit-identical to the oracle throughout."""
     w, h, d = 320, 24, 48
     cap = 20000
     rng = np.random.default_rng(5)
@@ -82,8 +85,8 @@ def test_sorted_fast_drift_strays_and_resort():
         rng.uniform(-1, 1, (cap, 3)).astype(np.float32) * np.array([30.0, 4.0, 6.0], np.float32)
     particles[:, 3] = 1.0
     drift = np.zeros((d, h, w, 4), np.float32)
-    drift[..., 0] = 50.0
-    drift[..., 2] = 7.0
+    drift[..., 0] = speed
+    drift[..., 2] = 0.14 * speed
     iters = 8
     st = OracleState(p, cap, iters)
     with fluid_amd.FluidEngine(p, particle_capacity=cap, pressure_iterations=iters) as eng:
@@ -96,11 +99,17 @@ def test_sorted_fast_drift_strays_and_resort():
         st.run_step()
         eng.upload_image(E.VELOCITIES_1, drift)
         st.velocities_1[...] = drift
-        for k in range(10):
+        binned = []
+        for k in range(steps):
             eng.run_step()
             st.run_step()
-            assert_state_equal(eng, st, ctx=f"drift step {k}: ")
-        assert eng.get_stat(E.STAT_PARTICLE_SORTS) >= 3
+            assert_state_equal(eng, st, ctx=f"drift {speed} step {k}: ")
+            binned.append(eng.get_stat(E.STAT_PARTICLE_BINNED))
+        sorts = eng.get_stat(E.STAT_PARTICLE_SORTS)
+        if speed < 10:
+            assert sorts >= 2 and binned[0] == 1, (sorts, binned)   # falling, it may end up suspended too
+        else:
+            assert binned[0] == 1 and binned[-1] == 0 and sorts <= 3, (sorts, binned)
 
 
 def test_sorted_particles_with_surface_prep_and_checkpoint(tmp_path):

@@ -89,7 +89,11 @@ struct fluid_ctx {
         bool stray_pending = false;
         PBinK bk{};
         int cur = 0;          // buffer that holds the particles: 0 = the arena's, 1 = alt
-        bool valid = false;   // ... sorted, slot_of[cur] and bin_start describe it
+        bool valid = false;   // ... in an order of its own: slot_of[cur] says which slot each one belongs to
+        bool binned = false;  // ... and bin_start describes it: 01 and 14 run their binned kernels
+        uint32_t steps_since_sort = 0;
+        uint32_t suspended = 0;  // 01 passes left before sorting is tried again (the flow outruns it)
+        uint32_t backoff = 64;   // ... the next time: doubles with every suspension, back to 64 after a calm spell
         bool failed = false;  // an allocation failed: slot order from now on
         uint64_t sorts = 0;
         double stray_steps = 0.0;  // sum over the steps since the last sort of the fraction of strays
@@ -845,6 +849,9 @@ void psort_release(fluid_ctx* c) {
 // the particles are (again) in slot order in the arena's buffer: after 00_init_particles and uploads
 void psort_reset(fluid_ctx* c) {
     c->ps.valid = false;
+    c->ps.binned = false;
+    c->ps.suspended = 0;
+    c->ps.backoff = 64;
     c->ps.cur = 0;
     c->ps.stray_pending = false;
     c->ps.stray_steps = 0.0;
@@ -899,40 +906,69 @@ int psort_sort(fluid_ctx* c) {
     HIP_TRY(c, hipGetLastError());
     ps.cur = dst;
     ps.valid = true;
+    ps.binned = true;
+    ps.steps_since_sort = 0;
     ps.sorts++;
     ps.stray_pending = false;
     ps.stray_steps = 0.0;
     return FLUID_OK;
 }
 // Before 01_update_densities: sort if the storage is not sorted yet, or when the strays have cost as much
-// as a sort would.  A stray costs 01 a global atomic and 14 its taps from global memory, about 70 ps; a sort
-// about 21 ps per slot (two passes over the buffer; measured with 1 G particles): so the storage is sorted
-// again once the fractions of strays of the steps since the last sort add up to 0.3 — with strays growing
-// linearly that is the interval that minimises sort + stray time.  The count of the last 01 is read one step
-// late, without waiting for it.
+// as a sort would.  Measured per particle slot (512^3 dam break and full tank): 01 + 14 cost 30 ps in slot
+// order and 10-15 ps freshly sorted; a stray costs 01 a global atomic and 14 its taps from global memory,
+// about 75 ps; a sort 21-34 ps (two passes over the buffer).  So the storage is sorted again once the
+// fractions of strays of the steps since the last sort add up to 0.3 — with strays growing linearly, r per
+// step, that is the interval that minimises sort + stray time, sqrt(2 * 34 * 75 * r) = 72 sqrt(r) ps per step.
+// Beyond r = 4 % per step that overhead eats what sorting saves (the collapse of the dam break is such a
+// flow): the storage goes back to slot order and 01 and 14 run their slot-order kernels for the next 64 steps,
+// after which sorting is tried again (128, 256 ... steps if it keeps failing).  The count of the last 01 is read one step late, without waiting for it.
+// back to slot order in the arena's buffer (sorting switched off, or suspended)
+int psort_to_slot_order(fluid_ctx* c) {
+    auto& ps = c->ps;
+    if (ps.valid) {
+        hipLaunchKernelGGL(k_pbin_to_slot_order, dim3((unsigned)((c->particle_capacity + 255) / 256)),
+                           dim3(256), 0, c->stream, c->particles(), ps.slot_of[ps.cur],
+                           c->particle_capacity, ps.cur ? c->particles_home() : ps.alt);
+        HIP_TRY(c, hipGetLastError());
+        if (!ps.cur) {  // the slot-ordered copy went to alt: bring it home
+            HIP_TRY(c, hipMemcpyAsync(c->particles_home(), ps.alt, c->particle_capacity * 16,
+                                      hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    const uint32_t suspended = ps.suspended, backoff = ps.backoff;
+    psort_reset(c);
+    ps.suspended = suspended;
+    ps.backoff = backoff;
+    return FLUID_OK;
+}
 int psort_before_count(fluid_ctx* c) {
     auto& ps = c->ps;
     if (!psort_wanted(c) || !psort_alloc(c)) {
-        if (ps.valid) {  // switched off while sorted: back to slot order
-            hipLaunchKernelGGL(k_pbin_to_slot_order, dim3((unsigned)((c->particle_capacity + 255) / 256)),
-                               dim3(256), 0, c->stream, c->particles(), ps.slot_of[ps.cur],
-                               c->particle_capacity, ps.cur ? c->particles_home() : ps.alt);
-            HIP_TRY(c, hipGetLastError());
-            if (!ps.cur) {  // the slot-ordered copy went to alt: bring it home
-                HIP_TRY(c, hipMemcpyAsync(c->particles_home(), ps.alt, c->particle_capacity * 16,
-                                          hipMemcpyDeviceToDevice, c->stream));
-            }
-            psort_reset(c);
-        }
-        return FLUID_OK;
+        ps.suspended = 0;
+        return psort_to_slot_order(c);
     }
     if (ps.stray_pending && hipEventQuery(ps.stray_ev) == hipSuccess) {
         ps.stray_steps += (double)ps.stray_host[1] / (double)c->particle_capacity;
         ps.stray_pending = false;
     }
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
+    ps.steps_since_sort++;
+    if (ps.suspended) {
+        if (--ps.suspended) return FLUID_OK;
+        return psort_sort(c);  // try again
+    }
     const bool again = mode == 3 || (mode != 4 && ps.stray_steps >= 0.3);
-    if (!ps.valid || again) return psort_sort(c);
+    if (ps.valid && ps.binned && again && mode != 3) {
+        // strays per step, from the triangle the fractions have summed to: sum = r T^2 / 2
+        const double T = (double)ps.steps_since_sort;
+        if (2.0 * ps.stray_steps / (T * T) > 0.04) {
+            ps.suspended = ps.backoff;
+            ps.backoff = std::min<uint32_t>(2 * ps.backoff, 2048);
+            return psort_to_slot_order(c);  // the slot-order kernels are fastest on slot order
+        }
+        if (T >= 32.0) ps.backoff = 64;  // a calm spell
+    }
+    if (!ps.valid || !ps.binned || again) return psort_sort(c);
     return FLUID_OK;
 }
 // 01 on the sorted storage; `marks` = pbricks() or null
@@ -1014,7 +1050,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             if (c->particle_capacity != 0) {
                 int rc = psort_before_count(c);
                 if (rc) return rc;
-                if (c->ps.valid) {
+                if (c->ps.binned) {
                     rc = psort_count(c, dens, c->pbricks(), bk);
                     if (rc) return rc;
                 } else {
@@ -1037,7 +1073,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             if (c->particle_capacity == 0) return FLUID_OK;
             int rc = psort_before_count(c);
             if (rc) return rc;
-            if (c->ps.valid) {
+            if (c->ps.binned) {
                 rc = psort_count(c, dens, nullptr, bk);
                 if (rc) return rc;
             } else {
@@ -1233,7 +1269,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_14_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
-            if (c->ps.valid) {
+            if (c->ps.binned) {
                 // few full bins (a sparse scene): two workgroups share a bin, each staging its tile (512^3 dam
                 // break: 0.36 -> 0.26 ms; the full tank loses 8 % that way)
                 const uint32_t parts = c->particle_capacity / (8u * PBIN_CELLS) < 256 * 32 ? 2u : 1u;
@@ -2470,9 +2506,12 @@ int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
         case FLUID_STAT_PARTICLE_SORTS:
             *value = c->ps.sorts;
             return FLUID_OK;
+        case FLUID_STAT_PARTICLE_BINNED:
+            *value = c->ps.binned ? 1 : 0;
+            return FLUID_OK;
         case FLUID_STAT_PARTICLE_STRAYS: {
             uint32_t v[2] = {0, 0};
-            if (c->ps.valid && c->ps.stray_count) {
+            if (c->ps.binned && c->ps.stray_count) {
                 HIP_TRY(c, hipMemcpyAsync(v, c->ps.stray_count, 8, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
             }

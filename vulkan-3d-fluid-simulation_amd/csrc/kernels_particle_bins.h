@@ -172,14 +172,35 @@ __global__ void k_pbin_to_slot_order(const float4* __restrict__ sorted, const ui
 // it holds has to stay, update_densities.comp:35 adds).  Strays (and the whole last segment, whose
 // particles counted nowhere when they were sorted): cell index appended to `strays`, added by
 // k01_binned_strays behind this kernel.  stray_count[0] = entries, [1] = particles found outside their bin.
+constexpr int K01_STRAY_BUF = 1024;  // stray keys a workgroup collects in LDS before it reserves list space
 template <bool ADD>
 __global__ void __launch_bounds__(256)
 k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bin_start, PBinK b,
            uint32_t* __restrict__ dens, GridK g, ParamsK p, uint8_t* __restrict__ particle_bricks, BrickK bk,
            uint32_t* __restrict__ strays, uint32_t* __restrict__ stray_count) {
     __shared__ uint32_t hist[PBIN_CELLS];
+    __shared__ uint32_t sbuf[K01_STRAY_BUF];
+    __shared__ uint32_t sn, sbase;  // keys in sbuf; where they go in the list
     __shared__ int any;
-    const int lane = (int)(threadIdx.x & 63u);
+    if (threadIdx.x == 0) sn = 0u;
+    __syncthreads();
+    // one reservation in the global list per flush, not per wavefront: the list's one counter is what a
+    // scene full of strays would otherwise queue up on.  Called by all threads.
+    auto flush = [&](bool real) {
+        __syncthreads();
+        const uint32_t n = sn;
+        if (n) {
+            if (threadIdx.x == 0) {
+                sbase = atomicAdd(&stray_count[0], n);
+                if (real) atomicAdd(&stray_count[1], n);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += 256) strays[sbase + i] = sbuf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) sn = 0u;
+            __syncthreads();
+        }
+    };
     for (uint32_t bin = blockIdx.x; bin <= b.bins; bin += gridDim.x) {
         const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
         if (s == e) continue;  // workgroup-uniform
@@ -189,36 +210,28 @@ k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bi
         for (int i = threadIdx.x; i < PBIN_CELLS; i += 256) hist[i] = 0u;
         if (threadIdx.x == 0) any = 0;
         __syncthreads();
+        int rounds = 0;
         for (uint32_t i0 = s; i0 < e; i0 += 256) {
             const uint32_t i = i0 + threadIdx.x;
-            bool stray = false;
-            uint32_t key = 0;
             if (i < e) {
                 const float4 q = particles[i];
                 int cx, cy, cz;
                 if (particle_cell(q, g, p, cx, cy, cz)) {
                     const int lx = cx - x0, ly = cy - y0, lz = cz - z0;
                     if (real && (unsigned)lx < (unsigned)PBIN_X && (unsigned)ly < (unsigned)PBIN_Y &&
-                        (unsigned)lz < (unsigned)PBIN_Z) {
+                        (unsigned)lz < (unsigned)PBIN_Z)
                         atomicAdd(&hist[lx + PBIN_X * (ly + PBIN_Y * lz)], 1u);
-                    } else {
-                        stray = true;
-                        key = (uint32_t)cidx(g, cx, cy, cz);
-                    }
+                    else
+                        sbuf[atomicAdd(&sn, 1u)] = (uint32_t)cidx(g, cx, cy, cz);
                 }
             }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(stray);
-            if (m) {  // one counter update per wavefront
-                uint32_t at = 0;
-                if (lane == __builtin_ctzll(m)) {
-                    at = atomicAdd(&stray_count[0], (uint32_t)__builtin_popcountll(m));
-                    if (real) atomicAdd(&stray_count[1], (uint32_t)__builtin_popcountll(m));
-                }
-                at = (uint32_t)__shfl((int)at, __builtin_ctzll(m), 64);
-                if (stray) strays[at + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = key;
+            // a round adds at most 256 keys: empty the buffer before a fourth could overflow it
+            if (++rounds == K01_STRAY_BUF / 256 - 1) {
+                flush(real);
+                rounds = 0;
             }
         }
-        __syncthreads();
+        flush(real);  // also the barrier in front of the histogram's readers
         if (real) {
             bool mine = false;
             for (int c = threadIdx.x; c < PBIN_CELLS; c += 256) {
