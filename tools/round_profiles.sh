@@ -19,4 +19,7 @@ python3 bench.py --grid 1024 1024 512 --iters 400 --steps 3 --warmup 1 --no-cpu-
 python3 tools/slab_rank_sim.py --ranks 2 4 8 --halo 8 > $OUT/slab_rank_rehearsal.txt 2>&1
 python3 tools/slab_one_rank_step.py > $OUT/slab_one_rank_step.txt 2>&1
 python3 tools/sor_time.py > $OUT/sor_time.txt 2>&1
+python3 tools/particle_sort_ab.py 512 20 > $OUT/particle_sort_ab.txt 2>&1
+python3 tools/particle_sort_longrun.py 512 400 50 > $OUT/particle_sort_longrun.txt 2>&1
+(python3 tools/surface_time.py 128 0; echo "--- one dispatch per pass (FLUID_OPT_SURFACE_KERNEL = 1 is the v4 kernel; the z-march single dispatches: 0.77 ms each) ---"; python3 tools/surface_time.py 128 1) > $OUT/surface_time.txt 2>&1
 tail -3 $OUT/dense_stats.log; tail -2 $OUT/sparse_stats.log; cat $OUT/slab_one_rank_step.txt

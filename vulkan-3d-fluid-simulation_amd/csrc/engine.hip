@@ -919,7 +919,7 @@ int psort_sort(fluid_ctx* c) {
 // about 75 ps; a sort 21-34 ps (two passes over the buffer).  So the storage is sorted again once the
 // fractions of strays of the steps since the last sort add up to 0.3 — with strays growing linearly, r per
 // step, that is the interval that minimises sort + stray time, sqrt(2 * 34 * 75 * r) = 72 sqrt(r) ps per step.
-// Beyond r = 4 % per step that overhead eats what sorting saves (the collapse of the dam break is such a
+// Beyond r = 3 % per step that overhead eats what sorting saves (the collapse of the dam break is such a
 // flow): the storage goes back to slot order and 01 and 14 run their slot-order kernels for the next 64 steps,
 // after which sorting is tried again (128, 256 ... steps if it keeps failing).  The count of the last 01 is read one step late, without waiting for it.
 // back to slot order in the arena's buffer (sorting switched off, or suspended)
@@ -961,7 +961,7 @@ int psort_before_count(fluid_ctx* c) {
     if (ps.valid && ps.binned && again && mode != 3) {
         // strays per step, from the triangle the fractions have summed to: sum = r T^2 / 2
         const double T = (double)ps.steps_since_sort;
-        if (2.0 * ps.stray_steps / (T * T) > 0.04) {
+        if (2.0 * ps.stray_steps / (T * T) > 0.03) {
             ps.suspended = ps.backoff;
             ps.backoff = std::min<uint32_t>(2 * ps.backoff, 2048);
             return psort_to_slot_order(c);  // the slot-order kernels are fastest on slot order
