@@ -246,7 +246,10 @@ def full_step_bench(size, iters, steps, device):
             eng.run_step()
         eng.sync()
         sections = {k: round(v[0] / tsteps, 4) for k, v in eng.section_times().items() if v[1]}
+        particles = {"stored_sorted_by_bin": bool(eng.get_stat(E.STAT_PARTICLE_BINNED)),
+                     "sorts": eng.get_stat(E.STAT_PARTICLE_SORTS)}
     return {
+        "particle_storage": particles,
         "workload": f"dam-break {size[0]}x{size[1]}x{size[2]}, {cap} particles, {iters} Jacobi iters "
                     f"(sparse: {round(100 * quiet)} % of the bricks are skipped, so this is a rate, not a "
                     "roofline statement: see full_step_dense)",
