@@ -519,7 +519,9 @@ typedef enum fluid_option {
     FLUID_OPT_QUIET_BRICKS = 3,    /* fluid_run_step with grouped passes: 0 = 07+08, 09+10+11 and 13     */
                                    /* skip bricks of 256x4x16 cells that have had no water in or   */
                                    /* next to them for three steps — a step changes nothing there  */
-                                   /* (default); 1 = process every cell                             */
+                                   /* (default); 1 = process every cell; 2 = as 0, with one workgroup */
+                                   /* per brick layer in the skipping passes whatever the grid size     */
+                                   /* (the default does that from 4096 bricks; tests)                   */
     FLUID_OPT_ADVECT_KERNEL = 4,   /* 07_advect: 0 = velocity sampler tiled into LDS (default), 1 = taps    */
                                    /* straight from global memory                                    */
     FLUID_OPT_SURFACE_KERNEL = 5,  /* 18_diffuse_float_densities: 0 = z-marching kernels (default): the loop */

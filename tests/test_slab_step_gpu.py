@@ -72,6 +72,8 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
                        grouped=grouped,
                        diffuse_mode=E.DIFFUSE_INTENDED if intended else E.DIFFUSE_REFERENCE_EXACT)
     sim.attach_torch_transport(device_memory=True)
+    if world == 3:   # one workgroup per brick layer in the skipping passes, as on grids of >= 4096 bricks
+        sim.engine.set_option(E.OPT_QUIET_BRICKS, 2)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0]), fast))

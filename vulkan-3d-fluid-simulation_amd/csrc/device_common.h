@@ -38,6 +38,10 @@ struct GridK {
     // them raises the context's halo-violation flag.  IMG_GHOST at most for VELOCITIES_1 itself; the wide
     // source of the fallback pass (fluid_sampler_wide_begin) has as many as the back-traces need.
     int sg_lo, sg_hi;
+    // Planes a workgroup of the brick-skipping passes walks (quiet_bricks.h): 1, or BRICK_Z while a step skips
+    // bricks — a launch over mostly skipped bricks costs what dispatching its workgroups costs, so there the
+    // workgroups are one per brick row instead of one per row of a plane.
+    int zl;
 };
 
 // Hot-path fields of the 264-byte params block (include/fluid_engine.h: fluid_params), passed by

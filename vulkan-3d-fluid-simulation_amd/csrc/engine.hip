@@ -199,6 +199,17 @@ struct fluid_ctx {
         return reinterpret_cast<T*>(arena + img[image].offset +
                                     (uint64_t)IMG_GHOST * g.plane * img[image].elem_bytes);
     }
+    // The grid as the brick-skipping passes get it (GridK::zl, quiet_bricks.h): while a step skips bricks a
+    // workgroup walks one brick layer instead of one plane — on grids with thousands of bricks, where
+    // dispatching sixteen times as many mostly idle workgroups is what such a pass costs (512^3: 55 us each,
+    // the step 5 % faster); with few bricks the finer workgroups win (256^3, 128^3: 8 % the other way).
+    GridK g_bricks() const {
+        GridK q = g;
+        q.zl = ((quiet_in_use || early_in_use) && (active_bytes >= 4096 || opt[FLUID_OPT_QUIET_BRICKS] == 2))
+                   ? BRICK_Z
+                   : 1;
+        return q;
+    }
     float4* particles_home() const { return reinterpret_cast<float4*>(arena + particles_offset); }
     float4* particles() const { return ps.cur ? ps.alt : particles_home(); }  // where they are stored now
     // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
@@ -573,7 +584,7 @@ int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), g, c->pk, rebuilt_mask, want_rhs, c->quiet_or_null(),
+                          c->bricks(), c->g_bricks(), c->pk, rebuilt_mask, want_rhs, c->quiet_or_null(),
                           c->flags() + 10);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = true;
@@ -618,7 +629,7 @@ int import_pressures(fluid_ctx* c, int image, int w) {
             n++;
         }
     k12_launch_import_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES), c->plane0<float>(image),
-                         c->work0(w), others[0], others[1], c->g, c->pk, c->quiet_or_null());
+                         c->work0(w), others[0], others[1], c->g_bricks(), c->pk, c->quiet_or_null());
     HIP_TRY(c, hipGetLastError());
     c->bg_valid[0] = c->bg_valid[1] = c->bg_valid[2] = true;
     return FLUID_OK;
@@ -636,7 +647,7 @@ int export_pressures(fluid_ctx* c, int w_even, int w_odd) {
                          w_even >= 0 ? c->work0(w_even) : nullptr,
                          w_odd >= 0 ? c->work0(w_odd) : nullptr,
                          c->plane0<float>(FLUID_IMG_PRESSURES_1),
-                         c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g, c->pk);
+                         c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g_bricks(), c->pk);
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -1018,7 +1029,11 @@ int run_section_impl(fluid_ctx* c, int section) {
     k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
     // kernels that can skip quiet bricks: one workgroup per brick row while skipping is on
     const int qchunks = c->quiet_in_use ? 4 : 1;
-    const dim3 qgrid((g.W + 64 * qchunks - 1) / (64 * qchunks), grid.y, grid.z);
+    // ... and per brick layer (GridK::zl): gq is the grid those kernels get, zgroups their grid's z extent
+    const GridK gq = c->g_bricks();
+    const unsigned zgroups = (unsigned)((g.Dl + gq.zl - 1) / gq.zl);
+    const dim3 qgrid((g.W + 64 * qchunks - 1) / (64 * qchunks), grid.y, zgroups);
+    const dim3 q4grid((g.W / 4 + 63) / 64, grid.y, zgroups);  // four cells per thread
 
     switch (section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
@@ -1040,8 +1055,13 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case STEP_01A_CLEAR_WHERE_PARTICLES_WERE:  // quiet_bricks.h; bricks() and pbricks() still hold the
                                                    // previous step's water / particle maps
-            hipLaunchKernelGGL(k_clear_density_where_particles_were, cell4_grid(g), block, 0, c->stream,
-                               dens, g, c->bricks(), c->pbricks(), bk);
+        {
+            GridK gb = g;  // brick-wise like the passes of g_bricks() (which this one precedes)
+            gb.zl = (c->active_bytes >= 4096 || c->opt[FLUID_OPT_QUIET_BRICKS] == 2) ? BRICK_Z : 1;
+            hipLaunchKernelGGL(k_clear_density_where_particles_were,
+                               dim3(q4grid.x, q4grid.y, (unsigned)((g.Dl + gb.zl - 1) / gb.zl)), block, 0,
+                               c->stream, dens, gb, c->bricks(), c->pbricks(), bk);
+        }
             c->dens_zero = true;  // the other bricks have not been counted into since the last full clear
             break;
         case STEP_01_UPDATE_DENSITIES_MARK_BRICKS: {
@@ -1088,14 +1108,14 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_02_UPDATE_WATER:
             if (g.W % 4 == 0)
-                hipLaunchKernelGGL(k02_update_water_v4, cell4_grid(g), block, 0, c->stream, dens,
-                                   newT, g, pk, c->early_or_null(), bk);
+                hipLaunchKernelGGL(k02_update_water_v4, q4grid, block, 0, c->stream, dens,
+                                   newT, gq, pk, c->early_or_null(), bk);
             else
                 hipLaunchKernelGGL(k02_update_water, grid, block, 0, c->stream, dens, newT, g, pk);
             break;
         case FLUID_SEC_03_UPDATE_AIR:
             if (g.W % 4 == 0)
-                hipLaunchKernelGGL(k03_update_air_v4, cell4_grid(g), block, 0, c->stream, newT, g,
+                hipLaunchKernelGGL(k03_update_air_v4, q4grid, block, 0, c->stream, newT, gq,
                                    pk, c->early_or_null(), bk);
             else
                 hipLaunchKernelGGL(k03_update_air, grid, block, 0, c->stream, newT, g, pk);
@@ -1110,16 +1130,16 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         // grouped passes of fluid_run_step (kernels_step_fused.h); not part of the public section ids
         case STEP_0405_EXTRAPOLATE:
-            hipLaunchKernelGGL(k0405_extrapolate, cell4_grid(g), block, 0, c->stream, T, newT, V1, V2,
-                               g, pk, c->early_or_null(), bk);
+            hipLaunchKernelGGL(k0405_extrapolate, q4grid, block, 0, c->stream, T, newT, V1, V2,
+                               gq, pk, c->early_or_null(), bk);
             break;
         case STEP_0405_APPLY:
-            hipLaunchKernelGGL(k0405_apply, cell4_grid(g), block, 0, c->stream, T, newT, V2, V1, g, pk,
+            hipLaunchKernelGGL(k0405_apply, q4grid, block, 0, c->stream, T, newT, V2, V1, gq, pk,
                                c->early_or_null(), bk);
             break;
         case STEP_0708_ADVECT_FORCES:
             if (c->opt[FLUID_OPT_ADVECT_KERNEL] == 1)
-                hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, g, pk,
+                hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, gq, pk,
                                    c->flags(), c->quiet_or_null(), bk, qchunks);
             else
                 hipLaunchKernelGGL(k07_advect_tiled<true>, dim3(qgrid.x, qgrid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
@@ -1130,7 +1150,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             c->touched(FLUID_IMG_DIVERGENCES);
             c->v1_w_zero = false;
             hipLaunchKernelGGL(k091011_solids_divergence, qgrid, block, 0, c->stream, T, V2, V1,
-                               c->plane0<float>(FLUID_IMG_DIVERGENCES), g, pk, c->quiet_or_null(), bk,
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), gq, pk, c->quiet_or_null(), bk,
                                qchunks);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
@@ -1176,8 +1196,8 @@ int run_section_impl(fluid_ctx* c, int section) {
             const int img = section == FLUID_SEC_12A_CLEAR_PRESSURES_1 ? FLUID_IMG_PRESSURES_1
                                                                        : FLUID_IMG_PRESSURES_2;
             if (!c->quiet_in_use) return fill_image(c, img, f32_bits(pk.p_air));
-            hipLaunchKernelGGL(k_fill_f32_unless_quiet, cell4_grid(g), block, 0, c->stream,
-                               c->plane0<float>(img), pk.p_air, g, c->quiet(), bk);
+            hipLaunchKernelGGL(k_fill_f32_unless_quiet, q4grid, block, 0, c->stream,
+                               c->plane0<float>(img), pk.p_air, gq, c->quiet(), bk);
             break;
         }
         case FLUID_SEC_12_SOLVE_PRESSURE: {
@@ -1196,7 +1216,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_13_FIX_DIVERGENCE:
             hipLaunchKernelGGL(k13_fix_divergence, qgrid, block, 0, c->stream, T,
-                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, g, pk, c->quiet_or_null(),
+                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, gq, pk, c->quiet_or_null(),
                                bk, qchunks);
             c->v1_w_zero = true;
             break;
@@ -1449,6 +1469,7 @@ int fluid_create(fluid_ctx** out, const fluid_create_info* info) {
     c->g.z0 = (int)z0;
     c->g.plane = (int64_t)p.fluid_size[0] * p.fluid_size[1];
     c->g.sg_lo = c->g.sg_hi = IMG_GHOST;
+    c->g.zl = 1;
     c->is_slab = dl != p.fluid_size[2];
     c->particle_capacity = capacity;
     c->surface = L.surf_cells != 0;
@@ -2112,7 +2133,7 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
                            ? c->ds_quiet
                            : (whole_step && group && !c->is_slab && fast_loop_possible(c) &&
                               c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT &&
-                              c->opt[FLUID_OPT_QUIET_BRICKS] == 0);
+                              c->opt[FLUID_OPT_QUIET_BRICKS] != 1);
     // the one-step test for the sections before 06 needs the previous step's water map in bricks():
     // nothing may have written the images since that step (quiet_valid still set)
     const bool early = c->driver_step ? c->ds_early
@@ -2228,7 +2249,7 @@ int fluid_step_begin(fluid_ctx* c, int section_list) {
     // skipping goes with the grouped passes (as in fluid_run_step): not when the caller runs the section list
     c->ds_quiet = !section_list && c->g.W % 4 == 0 && c->opt[FLUID_OPT_STEP_FUSION] == 0 &&
                   fast_loop_possible(c) &&
-                  c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT && c->opt[FLUID_OPT_QUIET_BRICKS] == 0;
+                  c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT && c->opt[FLUID_OPT_QUIET_BRICKS] != 1;
     c->ds_early = c->ds_quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid;
     c->quiet_in_use = c->early_in_use = false;
     c->ghost_bricks_valid = false;

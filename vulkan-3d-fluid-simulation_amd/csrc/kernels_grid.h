@@ -50,7 +50,8 @@ __global__ void k_fill_f32_unless_quiet(float* __restrict__ dst, float v, GridK 
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.W || y >= g.H) return;
-    *reinterpret_cast<float4*>(dst + cidx(g, x, y, (int)blockIdx.z)) = make_float4(v, v, v, v);
+    FLUID_FOR_PLANES_OF_WORKGROUP()
+    *reinterpret_cast<float4*>(dst + cidx(g, x, y, lz)) = make_float4(v, v, v, v);
 }
 
 // 02_update_water/update_water.comp:23-33
@@ -92,10 +93,11 @@ __global__ void k03_update_air(uint8_t* __restrict__ t, GridK g, ParamsK p) {
 #define FLUID_CELL4_THREAD()                                        \
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);      \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;            \
-    const int lz = blockIdx.z;                                      \
     if (x >= g.W || y >= g.H) return;                               \
-    const int64_t id = cidx(g, x, y, lz);                           \
-    const int gz = g.z0 + lz;
+    FLUID_FOR_PLANES_OF_WORKGROUP() {                               \
+        const int64_t id = cidx(g, x, y, lz);                       \
+        const int gz = g.z0 + lz;
+#define FLUID_CELL4_END }
 
 __global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* __restrict__ newT,
                                     GridK g, ParamsK p, const uint8_t* __restrict__ quiet, BrickK bk) {
@@ -106,6 +108,7 @@ __global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* 
     const uint32_t a = d.x > 0u ? p.t_water : p.t_inactive, b = d.y > 0u ? p.t_water : p.t_inactive;
     const uint32_t c = d.z > 0u ? p.t_water : p.t_inactive, e = d.w > 0u ? p.t_water : p.t_inactive;
     *reinterpret_cast<uint32_t*>(newT + id) = a | (b << 8) | (c << 16) | (e << 24);
+    FLUID_CELL4_END
 }
 
 __global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p,
@@ -151,6 +154,7 @@ __global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p,
         }
     }
     *reinterpret_cast<uint32_t*>(t + id) = out;
+    FLUID_CELL4_END
 }
 
 // 04_compute_extrapolated_velocities/extrapolated_velocities.comp:37-63

@@ -31,7 +31,7 @@ __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __res
                                uint32_t* __restrict__ x_extent) {
     FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // b_i-only passes of fluid_run_step (quiet_bricks.h)
     FLUID_V4_THREAD();
-    const int lz = blockIdx.z;
+    FLUID_FOR_PLANES_OF_WORKGROUP() {
     const int64_t id = cidx(g, x, y, lz);
     if (do_rhs) {
         const float4 d = *reinterpret_cast<const float4*>(div + id);
@@ -84,6 +84,7 @@ __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __res
             }
         }
     }
+    }  // planes of the workgroup
 }
 
 // PRESSURES_1 -> working buffer w0 (water: its value, else the cell's constant) and, where given, the
@@ -94,7 +95,8 @@ __global__ void k12_import_v4(const uint8_t* __restrict__ t, const float* __rest
                               const uint8_t* __restrict__ quiet, BrickK bk) {
     FLUID_LEAVE_IF_QUIET_V4(quiet, bk)  // quiet_bricks.h: the constants are in place already
     FLUID_V4_THREAD();
-    const int64_t id = cidx(g, x, y, (int)blockIdx.z);
+    FLUID_FOR_PLANES_OF_WORKGROUP() {
+    const int64_t id = cidx(g, x, y, lz);
     const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
     const float4 v = *reinterpret_cast<const float4*>(pimg + id);
     const float bg[4] = {background_value(byte_at(c, 0), p), background_value(byte_at(c, 1), p),
@@ -108,6 +110,7 @@ __global__ void k12_import_v4(const uint8_t* __restrict__ t, const float* __rest
     const float4 b4 = make_float4(bg[0], bg[1], bg[2], bg[3]);
     if (w1) *reinterpret_cast<float4*>(w1 + id) = b4;
     if (w2) *reinterpret_cast<float4*>(w2 + id) = b4;
+    }  // planes of the workgroup
 }
 
 // working buffers -> water cells of PRESSURES_1 (even iterate) and PRESSURES_2 (odd iterate)
@@ -115,11 +118,12 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
                               const float* __restrict__ w_odd, float* __restrict__ p1,
                               float* __restrict__ p2, GridK g, ParamsK p) {
     FLUID_V4_THREAD();
-    const int64_t id = cidx(g, x, y, (int)blockIdx.z);
+    FLUID_FOR_PLANES_OF_WORKGROUP() {
+    const int64_t id = cidx(g, x, y, lz);
     const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
     const bool w[4] = {byte_at(c, 0) == p.t_water, byte_at(c, 1) == p.t_water,
                        byte_at(c, 2) == p.t_water, byte_at(c, 3) == p.t_water};
-    if (!(w[0] || w[1] || w[2] || w[3])) return;  // pressure.comp:69: non-water cells are never written
+    if (!(w[0] || w[1] || w[2] || w[3])) continue;  // pressure.comp:69: non-water cells are never written
     const bool all = w[0] && w[1] && w[2] && w[3];
     auto put = [&](const float* src, float* dst) {
         const float4 v = *reinterpret_cast<const float4*>(src + id);
@@ -134,6 +138,7 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
     };
     if (w_even) put(w_even, p1);
     if (w_odd) put(w_odd, p2);
+    }  // planes of the workgroup
 }
 
 // ---- convergence read-out (not in the reference, which never looks at its residual) -----------------

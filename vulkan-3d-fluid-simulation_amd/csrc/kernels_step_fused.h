@@ -97,12 +97,13 @@ __global__ void k_clear_density_where_particles_were(uint32_t* __restrict__ dens
                                                      const uint8_t* __restrict__ old_water,
                                                      const uint8_t* __restrict__ old_particles, BrickK bk) {
     const int b = brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X, (int)(blockIdx.y * 4u) / BRICK_Y,
-                              (int)blockIdx.z / BRICK_Z);
+                              ((int)blockIdx.z * g.zl) / BRICK_Z);
     if ((old_water[b] | old_particles[b]) == 0) return;
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.W || y >= g.H) return;
-    *reinterpret_cast<uint4*>(dens + cidx(g, x, y, (int)blockIdx.z)) = make_uint4(0u, 0u, 0u, 0u);
+    FLUID_FOR_PLANES_OF_WORKGROUP()
+    *reinterpret_cast<uint4*>(dens + cidx(g, x, y, lz)) = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---- 04 + 05 ------------------------------------------------------------------------------------------
@@ -143,10 +144,11 @@ constexpr uint32_t STATE_ANY_EXTRAPOLATE = 0x2Au;  // bits of the three "2" stat
 #define FLUID_CELL4_ROW_THREAD()                                    \
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);      \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;            \
-    const int lz = blockIdx.z;                                      \
     if (x >= g.W || y >= g.H) return;                               \
-    const int64_t id = cidx(g, x, y, lz);                           \
-    const int gz = g.z0 + lz;
+    FLUID_FOR_PLANES_OF_WORKGROUP() {                               \
+        const int64_t id = cidx(g, x, y, lz);                       \
+        const int gz = g.z0 + lz;
+#define FLUID_CELL4_ROW_END }
 
 // 04 where 05 needs it: VELOCITIES_2[cell] = mean velocity of the cell's WATER neighbours
 // (extrapolated_velocities.comp:37-63) for cells with a component in state VELOCITY_EXTRAPOLATE.
@@ -156,7 +158,7 @@ __global__ void k0405_extrapolate(const uint8_t* __restrict__ oldT, const uint8_
     FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
     FLUID_CELL4_ROW_THREAD();
     const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);
-    if ((st & (STATE_ANY_EXTRAPOLATE * 0x01010101u)) == 0u) return;
+    if ((st & (STATE_ANY_EXTRAPOLATE * 0x01010101u)) == 0u) continue;
     for (int i = 0; i < 4; i++) {
         if (((st >> (8 * i)) & STATE_ANY_EXTRAPOLATE) == 0u) continue;
         const int xi = x + i;
@@ -186,6 +188,7 @@ __global__ void k0405_extrapolate(const uint8_t* __restrict__ oldT, const uint8_
         }
         v2[id + i] = o;  // :62
     }
+    FLUID_CELL4_ROW_END
 }
 
 // 05 where it changes anything (extrapolate_velocities.comp:88-108); cells without a RESET /
@@ -197,7 +200,7 @@ __global__ void k0405_apply(const uint8_t* __restrict__ oldT, const uint8_t* __r
     FLUID_CELL4_ROW_THREAD();
     (void)gz;
     const uint32_t st = activity_states4(oldT, newT, g, p, x, y, lz, id);
-    if (st == 0u) return;
+    if (st == 0u) continue;
     for (int i = 0; i < 4; i++) {
         const uint32_t s = (st >> (8 * i)) & 0x3Fu;
         if (s == 0u) continue;
@@ -216,6 +219,7 @@ __global__ void k0405_apply(const uint8_t* __restrict__ oldT, const uint8_t* __r
         }
         v1[id + i] = make_float4(cur[0], cur[1], cur[2], 0.0f);  // :108
     }
+    FLUID_CELL4_ROW_END
 }
 
 // ---- 09 (as written) + 10 + 11 -------------------------------------------------------------------------

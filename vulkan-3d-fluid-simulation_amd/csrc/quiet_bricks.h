@@ -36,15 +36,21 @@ constexpr uint32_t QUIET_MIN_STREAK = 3;
 #define FLUID_LEAVE_IF_QUIET(quiet, bk, xchunks)                                                 \
     if (quiet) {                                                                                 \
         const int qb_ = brick_index(bk, (int)(blockIdx.x * 64u * (unsigned)(xchunks)) / BRICK_X, \
-                                    (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z); \
+                                    (int)(blockIdx.y * 4u) / BRICK_Y,                            \
+                                    ((int)blockIdx.z * g.zl) / BRICK_Z);                         \
         if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                    \
     }
+
+// the planes of a workgroup: blockIdx.z counts groups of g.zl planes (GridK::zl: 1, or BRICK_Z while bricks
+// are being skipped — then a workgroup stays inside one brick and the test above holds for all its planes)
+#define FLUID_FOR_PLANES_OF_WORKGROUP() \
+    for (int lz = (int)blockIdx.z * g.zl, lz_end_ = min(lz + g.zl, g.Dl); lz < lz_end_; lz++)
 
 // cell loop of those kernels: x runs over the workgroup's `xchunks` chunks of 64 cells
 #define FLUID_FOR_CELLS_OF_ROW(xchunks)                                              \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;                             \
-    const int lz = blockIdx.z;                                                       \
     if (y >= g.H) return;                                                            \
+    FLUID_FOR_PLANES_OF_WORKGROUP()                                                  \
     for (int xc_ = 0; xc_ < (xchunks); xc_++) {                                      \
         const int x = ((int)blockIdx.x * (xchunks) + xc_) * 64 + (int)threadIdx.x;   \
         if (x >= g.W) break;
@@ -54,7 +60,8 @@ constexpr uint32_t QUIET_MIN_STREAK = 3;
 #define FLUID_LEAVE_IF_QUIET_V4(quiet, bk)                                                         \
     if (quiet) {                                                                                   \
         const int qb_ = brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X,                        \
-                                    (int)(blockIdx.y * 4u) / BRICK_Y, (int)blockIdx.z / BRICK_Z);  \
+                                    (int)(blockIdx.y * 4u) / BRICK_Y,                              \
+                                    ((int)blockIdx.z * g.zl) / BRICK_Z);                           \
         if ((uint32_t)quiet[qb_] >= QUIET_MIN_STREAK) return;                                      \
     }
 
