@@ -133,6 +133,7 @@ struct fluid_ctx {
     uint64_t early_offset = 0;    // one byte per brick: 255 = skipped by 02 / 03 / 04+05 of this step
     uint64_t pbricks_offset = 0;  // one byte per brick: a particle was counted there in this step
     bool early_in_use = false;    // inside fluid_run_step, between 01 and 06
+    bool early_step = false;      // ... and until the step's mask pass: early() says where 02 ... 06 left the types alone
     bool early_wanted = false;    // the running 01 pass also derives the one-step test from its marks
     bool pbricks_valid = false;   // pbricks() marks every brick in which the last 01 counted a particle
     // a step driven section by section from outside (fluid_step_begin / _end: the Z-slab driver), with the
@@ -574,6 +575,12 @@ float oob_value(const fluid_ctx* c) {
 // of this step exists, because the quiet-brick map needs the activity bricks).
 int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
     const bool want_rhs = !mask_only && !c->rhs_valid;
+    // The mask pass of a step may leave the bricks alone that 02 ... 05 skipped (the one-step test,
+    // quiet_bricks.h): their cell types are the previous step's (06 copied what was there already), they hold
+    // no water — every mask byte is MASK_DRY as before, the brick stays inactive — and the previous mask
+    // was complete (the test needs mask_valid).
+    const uint8_t* unchanged = (mask_only && c->early_step) ? c->early() : nullptr;
+    c->early_step = false;
     if (c->mask_valid && !want_rhs) return FLUID_OK;
     const GridK& g = c->g;
     const bool rebuilt_mask = !c->mask_valid;
@@ -584,8 +591,8 @@ int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), c->g_bricks(), c->pk, rebuilt_mask, want_rhs, c->quiet_or_null(),
-                          c->flags() + 10);
+                          c->bricks(), c->g_bricks(), c->pk, rebuilt_mask, want_rhs,
+                          rebuilt_mask ? unchanged : c->quiet_or_null(), c->flags() + 10);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = true;
     if (want_rhs) c->rhs_valid = true;
@@ -2155,7 +2162,7 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
             rc = timed_section(c, s, STEP_01_UPDATE_DENSITIES_MARK_BRICKS);
             c->early_wanted = false;
             if (rc) return rc;
-            c->early_in_use = early;
+            c->early_in_use = c->early_step = early;
             s += 1;
             continue;
         }

@@ -20,7 +20,7 @@ void k12_launch_prepare_v4(hipStream_t s, const uint8_t* t, const float* div, ui
     BrickK bk;
     k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
     hipLaunchKernelGGL(k12_prepare_v4, v4_grid_zl(g), v4_block(), 0, s, t, div, mask, rhs, bricks,
-                       bk, g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0, do_mask ? nullptr : quiet, x_extent);
+                       bk, g, p, do_mask ? 1 : 0, do_rhs ? 1 : 0, quiet, x_extent);
 }
 
 void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, float* w0, float* w1,
