@@ -496,7 +496,9 @@ def main():
     assert dispatches == sweeps, (dispatches, sweeps)  # loop sections count their sweeps
     # The loop section runs two sweeps per kernel launch (temporal blocking) unless --no-fuse: one
     # launch then carries 2 x 13 B/cell of algorithmic traffic.  HIP events bracket the whole loop
-    # section (prepare / import / export passes included), so the per-launch figure is conservative.
+    # section (import / export passes included), so the per-launch figure is conservative.  The loop's mask /
+    # b_i pass (k12_prepare) runs only when CELL_TYPES / DIVERGENCES change: once per step in a simulation
+    # (0.45 ms at 512^3, 1 % of a 200-iteration loop; inside full_step and full_step_dense), once in all here.
     fused = (not args.no_fuse) and w % 4 == 0 and w <= 1024
     sweeps_per_launch = 2 if fused else 1
     launch_ms = loop_ms / sweeps * sweeps_per_launch

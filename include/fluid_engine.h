@@ -304,7 +304,12 @@ int fluid_run_step(fluid_ctx* ctx);
 /* Fence: wait until everything enqueued so far has executed (replaces fence wait main.cpp:124). */
 int fluid_sync(fluid_ctx* ctx);
 
-/* ---- timing --------------------------------------------------------------------------------- */
+/* ---- timing and tracing --------------------------------------------------------------------- */
+/* The name the reference's section lists give a section ("07_advect", fluid_flow_sections.h:139-388), or NULL.
+ * With FLUID_ROCTX=1 in the environment every section runs inside a roctx range of that name (libroctx64,
+ * loaded on first use): rocprofv3 --marker-trace --kernel-trace then attributes kernels to list entries. */
+const char* fluid_section_name(int section_id);
+
 /* When enabled, every run_section / loop records HIP events on the context's stream.           */
 int fluid_enable_timing(fluid_ctx* ctx, int enabled);
 /* Accumulated device milliseconds and launch count of a section since the last reset.          */

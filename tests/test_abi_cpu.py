@@ -151,3 +151,17 @@ def test_section_table_follows_the_reference_lists():
         m = re.search(r"FLUID_SEC_%s\w* = (\d+)" % n.split("_")[0].upper(), text)
         assert m, n
     assert len(names) == 26
+
+
+def test_section_names_are_the_reference_list_spellings():
+    """fluid_section_name: the strings the reference's section lists use (fluid_flow_sections.h:139-388), the
+    ones roctx ranges carry under FLUID_ROCTX=1; needs no GPU."""
+    import ctypes as C
+
+    from fluid_amd import engine as E
+    lib = E.load_library()
+    lib.fluid_section_name.restype = C.c_char_p
+    lib.fluid_section_name.argtypes = [C.c_int]
+    for i, name in enumerate(E.SECTION_NAMES):
+        assert lib.fluid_section_name(i).decode() == name
+    assert lib.fluid_section_name(-1) is None and lib.fluid_section_name(len(E.SECTION_NAMES)) is None

@@ -4,6 +4,7 @@
 //
 // gfx950 only.  There is no CPU path in this library: every section either launches a HIP kernel
 // or returns an error.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -449,11 +450,55 @@ int fold_timers(fluid_ctx* c) {
     return FLUID_OK;
 }
 
+// names of the sections as the reference's section lists spell them (fluid_flow_sections.h:139-388)
+const char* const kSectionNames[FLUID_SECTION_COUNT] = {
+    "init_clear_velocities_1", "init_clear_cell_types", "00_init_particles",
+    "01a_clear_particle_densities", "01_update_densities", "02_update_water", "03_update_air",
+    "04_compute_extrapolated_velocities", "05_set_extrapolated_velocities", "06_update_cell_types",
+    "07_advect", "08_forces", "09_diffuse", "10_solids", "11_compute_divergence",
+    "12a_clear_pressures_1", "12b_clear_pressures_2", "12_solve_pressure", "13_fix_divergence",
+    "14_particles", "14a_clear_detailed_densities", "15_update_detailed_densities",
+    "16_compute_detailed_densities_inertia", "17_compute_float_densities", "18_diffuse_float_densities",
+    "init_clear_detailed_densities_inertia"};
+
+// Tracing: with FLUID_ROCTX=1 in the environment every section is a roctx range named
+// after it, so `rocprofv3 --marker-trace --kernel-trace` shows which kernels belong to which entry of the
+// section list.  The roctx library is loaded on first use; without the variable (or the library) nothing happens.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("FLUID_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        // rocprofv3 listens to the SDK's roctx; the roctracer one serves the older tools
+        void* lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+
 struct SectionTimer {
     fluid_ctx* c;
     TimerSlot slot;
     bool active = false;
+    bool range = false;
+    ~SectionTimer() {
+        if (range) roctx().pop();
+    }
     int begin(int section) {
+        if (roctx().push && section >= 0 && section < FLUID_SECTION_COUNT) {
+            roctx().push(kSectionNames[section]);
+            range = true;
+        }
         if (!c->timing) return FLUID_OK;
         if (c->pending.size() >= 8192) {
             int rc = fold_timers(c);
@@ -472,6 +517,10 @@ struct SectionTimer {
         return FLUID_OK;
     }
     int end() {
+        if (range) {
+            roctx().pop();
+            range = false;
+        }
         if (!active) return FLUID_OK;
         HIP_TRY(c, hipEventRecord(slot.stop, c->stream));
         c->pending.push_back(slot);
@@ -1352,6 +1401,10 @@ uint8_t* image_host_base(const fluid_ctx* c, int image_id) {
 extern "C" {
 
 int fluid_abi_version(void) { return FLUID_ENGINE_ABI_VERSION; }
+
+const char* fluid_section_name(int section_id) {
+    return (section_id >= 0 && section_id < FLUID_SECTION_COUNT) ? kSectionNames[section_id] : nullptr;
+}
 
 int fluid_params_default(fluid_params* p, uint32_t w, uint32_t h, uint32_t d, uint32_t capacity) {
     if (!p) return FLUID_ERR_INVALID_ARG;

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "fluid_run_section", "fluid_run_section_loop", "fluid_run_section_group", "fluid_clear_image",
     "fluid_run_surface_diffuse_dispatch", "fluid_set_pressure_solver",
     "fluid_run_pressure_dispatch", "fluid_run_init",
-    "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms",
+    "fluid_run_step", "fluid_sync", "fluid_enable_timing", "fluid_section_time_ms", "fluid_section_name",
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_notify_ghost_planes_written", "fluid_get_stat", "fluid_pressure_residual",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
@@ -160,6 +160,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_sync": (C.c_int, [vp]),
         "fluid_enable_timing": (C.c_int, [vp, C.c_int]),
         "fluid_section_time_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "fluid_section_name": (C.c_char_p, [C.c_int]),
         "fluid_reset_timing": (C.c_int, [vp]),
         "fluid_image_plane_ptr": (C.c_int, [vp, C.c_int, i32, C.POINTER(vp), C.POINTER(u64)]),
         "fluid_notify_image_written": (C.c_int, [vp, C.c_int]),
