@@ -414,6 +414,7 @@ struct LoopbackTransport : Transport {
 // ===========================================================================================================
 struct fluid_slab {
     uint32_t rank = 0, world = 1;
+    int device = -1;       // HIP device of the engine backend (-1: the compute is not on a device)
     int lo = -1, hi = -1;  // ranks of the neighbours below / above, -1 = domain face
     uint32_t W = 0, H = 0, D = 0, z0 = 0, dl = 0, thinnest = 0;
     uint64_t capacity = 0;
@@ -1035,6 +1036,10 @@ int fluid_slab_create(fluid_slab** out, const fluid_slab_create_info* info) {
     if (info->diffuse_mode != FLUID_DIFFUSE_REFERENCE_EXACT) (void)fluid_set_diffuse_mode(be->c, info->diffuse_mode);
     if (s->world > 1) (void)fluid_set_sampler_halo(be->c, s->sampler_halo);
     s->be = std::move(be);
+    if (info->device >= 0)
+        s->device = info->device;
+    else
+        (void)hipGetDevice(&s->device);
     *out = s.release();
     return FLUID_OK;
 }
@@ -1118,6 +1123,7 @@ int fluid_slab_rccl_unique_id(void* id_out) {
 int fluid_slab_attach_rccl(fluid_slab* s, const void* id_bytes) {
     if (!s) return FLUID_ERR_INVALID_ARG;
     if (!id_bytes) return s->fail(FLUID_ERR_INVALID_ARG, "null unique id");
+    if (s->device >= 0) HIPS(s, hipSetDevice(s->device));  // the communicator binds to the current device
     if (!s->be->on_device())
         return s->fail(FLUID_ERR_UNSUPPORTED, "RCCL moves device memory: this driver computes on the host");
     std::string why;
@@ -1163,6 +1169,7 @@ int fluid_slab_attach_loopback(fluid_slab* s, int has_lower, int has_upper) {
 
 int fluid_slab_attach_rccl_self(fluid_slab* s, int has_lower, int has_upper) {
     if (!s) return FLUID_ERR_INVALID_ARG;
+    if (s->device >= 0) HIPS(s, hipSetDevice(s->device));  // the communicator binds to the current device
     if (!s->be->on_device())
         return s->fail(FLUID_ERR_UNSUPPORTED, "RCCL moves device memory: this driver computes on the host");
     std::string why;
