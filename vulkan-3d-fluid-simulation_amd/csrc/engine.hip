@@ -1088,8 +1088,12 @@ int run_section_impl(fluid_ctx* c, int section) {
     // ... and per brick layer (GridK::zl): gq is the grid those kernels get, zgroups their grid's z extent
     const GridK gq = c->g_bricks();
     const unsigned zgroups = (unsigned)((g.Dl + gq.zl - 1) / gq.zl);
-    const dim3 qgrid((g.W + 64 * qchunks - 1) / (64 * qchunks), grid.y, zgroups);
     const dim3 q4grid((g.W / 4 + 63) / 64, grid.y, zgroups);  // four cells per thread
+    // the passes with real work per cell (09+10+11, 13) keep four times as many workgroups of a quarter of a
+    // brick layer each: with whole layers the few active bricks finish later than the dispatch saves
+    GridK gqh = gq;
+    gqh.zl = gq.zl > 1 ? BRICK_Z / 4 : 1;
+    const dim3 qgrid((g.W + 64 * qchunks - 1) / (64 * qchunks), grid.y, (unsigned)((g.Dl + gqh.zl - 1) / gqh.zl));
 
     switch (section) {
         case FLUID_SEC_INIT_CLEAR_VELOCITIES_1:
@@ -1195,7 +1199,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             break;
         case STEP_0708_ADVECT_FORCES:
             if (c->opt[FLUID_OPT_ADVECT_KERNEL] == 1)
-                hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, gq, pk,
+                hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, gqh, pk,
                                    c->flags(), c->quiet_or_null(), bk, qchunks);
             else
                 hipLaunchKernelGGL(k07_advect_tiled<true>, dim3(qgrid.x, qgrid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
@@ -1206,7 +1210,7 @@ int run_section_impl(fluid_ctx* c, int section) {
             c->touched(FLUID_IMG_DIVERGENCES);
             c->v1_w_zero = false;
             hipLaunchKernelGGL(k091011_solids_divergence, qgrid, block, 0, c->stream, T, V2, V1,
-                               c->plane0<float>(FLUID_IMG_DIVERGENCES), gq, pk, c->quiet_or_null(), bk,
+                               c->plane0<float>(FLUID_IMG_DIVERGENCES), gqh, pk, c->quiet_or_null(), bk,
                                qchunks);
             break;
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
@@ -1272,7 +1276,7 @@ int run_section_impl(fluid_ctx* c, int section) {
         }
         case FLUID_SEC_13_FIX_DIVERGENCE:
             hipLaunchKernelGGL(k13_fix_divergence, qgrid, block, 0, c->stream, T,
-                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, gq, pk, c->quiet_or_null(),
+                               c->plane0<float>(FLUID_IMG_PRESSURES_2), V1, gqh, pk, c->quiet_or_null(),
                                bk, qchunks);
             c->v1_w_zero = true;
             break;
