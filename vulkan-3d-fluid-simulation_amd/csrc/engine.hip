@@ -703,7 +703,8 @@ int export_pressures(fluid_ctx* c, int w_even, int w_odd) {
                          w_even >= 0 ? c->work0(w_even) : nullptr,
                          w_odd >= 0 ? c->work0(w_odd) : nullptr,
                          c->plane0<float>(FLUID_IMG_PRESSURES_1),
-                         c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g_bricks(), c->pk);
+                         c->plane0<float>(FLUID_IMG_PRESSURES_2), c->g_bricks(), c->pk,
+                         c->mask_valid ? c->bricks() : nullptr);  // the bricks of these very cell types
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }

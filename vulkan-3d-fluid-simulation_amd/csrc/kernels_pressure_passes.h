@@ -116,7 +116,13 @@ __global__ void k12_import_v4(const uint8_t* __restrict__ t, const float* __rest
 // working buffers -> water cells of PRESSURES_1 (even iterate) and PRESSURES_2 (odd iterate)
 __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __restrict__ w_even,
                               const float* __restrict__ w_odd, float* __restrict__ p1,
-                              float* __restrict__ p2, GridK g, ParamsK p) {
+                              float* __restrict__ p2, GridK g, ParamsK p,
+                              const uint8_t* __restrict__ active, BrickK bk) {
+    // `active` (optional): the activity bricks of the cell types being read — a brick without water has
+    // nothing to export.  Needs the workgroup inside one brick (g.zl planes of one layer).
+    if (active && active[brick_index(bk, (int)(blockIdx.x * 256u) / BRICK_X, (int)(blockIdx.y * 4u) / BRICK_Y,
+                                     ((int)blockIdx.z * g.zl) / BRICK_Z)] == 0)
+        return;
     FLUID_V4_THREAD();
     FLUID_FOR_PLANES_OF_WORKGROUP() {
     const int64_t id = cidx(g, x, y, lz);

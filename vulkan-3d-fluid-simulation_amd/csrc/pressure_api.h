@@ -40,7 +40,8 @@ void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, fl
                           float* w2, const GridK& g, const ParamsK& p, const uint8_t* quiet = nullptr);
 // `quiet`: per-brick streaks (quiet_bricks.h) — workgroups in a quiet brick leave at once; null = all
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
-                          float* p1, float* p2, const GridK& g, const ParamsK& p);
+                          float* p1, float* p2, const GridK& g, const ParamsK& p,
+                          const uint8_t* active);
 // out[0..6] = {bricks with water, y brick range lo, hi, z brick range lo, hi, x CELL range lo, hi (from
 // the mask pass's x_extent)}
 // one colour (0 / 1) of a red-black SOR iteration in place on a pressure image (opt-in solver)

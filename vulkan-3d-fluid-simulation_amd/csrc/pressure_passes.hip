@@ -32,9 +32,11 @@ void k12_launch_import_v4(hipStream_t s, const uint8_t* t, const float* pimg, fl
 }
 
 void k12_launch_export_v4(hipStream_t s, const uint8_t* t, const float* w_even, const float* w_odd,
-                          float* p1, float* p2, const GridK& g, const ParamsK& p) {
+                          float* p1, float* p2, const GridK& g, const ParamsK& p, const uint8_t* active) {
+    BrickK bk;
+    k12_brick_dims(g.W, g.H, g.Dl, bk.nbx, bk.nby, bk.nbz);
     hipLaunchKernelGGL(k12_export_v4, v4_grid_zl(g), v4_block(), 0, s, t, w_even, w_odd, p1, p2, g,
-                       p);
+                       p, active, bk);
 }
 
 void k12_launch_residual(hipStream_t s, const uint8_t* t, const float* div, const float* pimg,
