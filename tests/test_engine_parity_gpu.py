@@ -605,11 +605,14 @@ def test_pressure_split_passes_equal_whole_passes(size):
 
 
 @pytest.mark.parametrize("iters", [2, 3, 6])
-def test_pressure_division_special_values(iters):
+@pytest.mark.parametrize("tiny", [True, False])
+def test_pressure_division_special_values(iters, tiny):
     """The fused kernel replaces the IEEE division n / aii by a three-instruction exact quotient plus
     v_div_fixup_f32 (kernels_pressure_fused.h).  Isolated water cells with every neighbour count
     aii = 0..6 and numerators that are zeros, infinities, NaN, denormals, the extremes of the normal
-    range and values on both sides of the kernel's 2^-90 guard: bit-identical to the oracle."""
+    range and values on both sides of the kernel's 2^-100 guard: bit-identical to the oracle.  A wavefront
+    that holds a tiny non-zero numerator takes the IEEE sequence for all its lanes, so the second variant
+    leaves those out: zeros, infinities, NaN and the extremes then go through the short quotient."""
     w, h, d = 64, 48, 12
     p = default_params(w, h, d, 0)
     p.time_delta = 1.0      # b_i = ((div * rho) * dx) / dt = div exactly
@@ -620,8 +623,11 @@ def test_pressure_division_special_values(iters):
     st.cell_types[...] = CELL_AIR
     specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-40, -3e-39,
                          2.0 ** -126, -(2.0 ** -126), 1.7e-38, 2.0 ** -100, 2.0 ** -91, -(2.0 ** -90),
-                         2.0 ** -89, 3.0, -7.0, 1.0 / 3.0, 3.4028234e38, -3.4028234e38, 1e30, 5e-324],
+                         2.0 ** -89, 3.0, -7.0, 1.0 / 3.0, 3.4028234e38, -3.4028234e38, 1e30, 5e-324,
+                         2.0 ** -101, -(2.0 ** -100) * 1.5, 2.0 ** -99, -(2.0 ** -100) * (1 - 2.0 ** -24)],
                         np.float32)
+    if not tiny:
+        specials = specials[(specials == 0) | ~(np.abs(specials) < 2.0 ** -100)]   # keeps NaN and inf
     solid_dirs = [(0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0)]
     k = 0
     cells = []

@@ -18,14 +18,17 @@ p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
 p.particle_spawn_cube_size[:] = size
 
 
-def timed(eng, label, its=100):
-    eng.solve_pressure(20)
-    eng.enable_timing(True)
-    eng.reset_timing()
-    eng.solve_pressure(its)
-    ms, _ = eng.section_time_ms("12_solve_pressure")
-    eng.enable_timing(False)
-    print(f"{label:60s} {ms / its:.4f} ms per sweep (passes included)", flush=True)
+def timed(eng, label, its=400):
+    eng.solve_pressure(40)
+    vals = []
+    for _ in range(3):
+        eng.enable_timing(True)
+        eng.reset_timing()
+        eng.solve_pressure(its)
+        ms, _ = eng.section_time_ms("12_solve_pressure")
+        eng.enable_timing(False)
+        vals.append(ms / its)
+    print(f"{label:60s} " + "  ".join(f"{v:.4f}" for v in vals) + " ms per sweep (passes included)", flush=True)
 
 
 with fluid_amd.FluidEngine(p, particle_capacity=vol, pressure_iterations=20) as eng:

@@ -54,11 +54,14 @@ __device__ __forceinline__ void st_f4(float* base, unsigned byte_off, float4 v) 
 //     q0 = n * r;  e = fma(-q0, a, n);  q = fma(e, r, q0)          with r = RN(1/a) from a table
 // (Markstein's correction step: e is the exact remainder).  tests/divide_small_int_check.c compares
 // this chain with n / a for ALL 2^32 fp32 values of n and a = 1..6 on the CPU: bit-identical except
-// for a = 6 with |n| < 2^-125; a wave-uniform test sends any wavefront holding |n| < 2^-90 down the
-// IEEE path instead (never taken in practice; 2^-90 also keeps e out of the denormal range, so the
-// result does not depend on the kernel's denormal mode).  v_div_fixup_f32 — the last instruction of
-// the IEEE sequence, with the same operands — supplies the IEEE results for n = +-0, inf, NaN and
-// a = 0 (inf / NaN), bit for bit what the division gives.
+// for a = 6 with |n| < 2^-125; a wave-uniform test sends any wavefront holding 0 < |n| < 2^-100 down the
+// IEEE path instead (2^-100 also keeps e out of the denormal range, so the result does not depend on the
+// kernel's denormal mode).  v_div_fixup_f32 — the last instruction of the IEEE sequence, with the same
+// operands — supplies the IEEE results for n = +-0, inf, NaN and a = 0 (inf / NaN), bit for bit what the
+// division gives.  The test reads the exponents (v_frexp_exp_i32_f32: 0 for zero, inf and NaN) so that an
+// exact zero does not count as tiny: numerators of exactly 0 are everyday — dry lanes, cells that touch only
+// solids where the divergence is 0 — and with a test on |n| alone they sent a full tank's wavefronts down
+// the slow path (13 % of the launch, tools/dense_jacobi_probe.py).
 struct DivEntry {
     float a, r;
 };
@@ -103,9 +106,16 @@ __device__ __forceinline__ DivPairs div_pairs(uint32_t m, const FLUID_LDS char* 
 }
 // the four quotients of a lane: n / aii, aii = bytes of m, (aii, RN(1 / aii)) = d
 __device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const DivPairs& d) {
-    const float tiny = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+    // two steps, both wave-uniform: the cheap look (three v_min with |.|) finds zeros too; only then the exponents
+    const float least = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+    bool ieee = false;
+    if (__builtin_amdgcn_ballot_w64(least < 0x1p-100f) != 0ull) {
+        const int ex = min(min(__builtin_amdgcn_frexp_expf(n.x), __builtin_amdgcn_frexp_expf(n.y)),
+                           min(__builtin_amdgcn_frexp_expf(n.z), __builtin_amdgcn_frexp_expf(n.w)));
+        ieee = __builtin_amdgcn_ballot_w64(ex < -99) != 0ull;  // some 0 < |n| < 2^-100 in this wavefront
+    }
     float4 o;
-    if (__builtin_amdgcn_ballot_w64(tiny < 0x1p-90f) == 0ull) {
+    if (!ieee) {
         o.x = div_small_int(n.x, d.c[0]);
         o.y = div_small_int(n.y, d.c[1]);
         o.z = div_small_int(n.z, d.c[2]);
