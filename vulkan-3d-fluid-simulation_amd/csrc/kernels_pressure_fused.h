@@ -54,8 +54,8 @@ __device__ __forceinline__ void st_f4(float* base, unsigned byte_off, float4 v) 
 //     q0 = n * r;  e = fma(-q0, a, n);  q = fma(e, r, q0)          with r = RN(1/a) from a table
 // (Markstein's correction step: e is the exact remainder).  tests/divide_small_int_check.c compares
 // this chain with n / a for ALL 2^32 fp32 values of n and a = 1..6 on the CPU: bit-identical except
-// for a = 6 with |n| < 2^-125; a wave-uniform test sends any wavefront holding 0 < |n| < 2^-100 down the
-// IEEE path instead (2^-100 also keeps e out of the denormal range, so the result does not depend on the
+// for a = 6 with |n| < 2^-125; a wave-uniform test sends any wavefront holding 0 < |n| < 2^-100 (kernels of one
+// x tile: |n| < 2^-100, zeros included; canon_div4) down the IEEE path instead (2^-100 also keeps e out of the denormal range, so the result does not depend on the
 // kernel's denormal mode).  v_div_fixup_f32 — the last instruction of the IEEE sequence, with the same
 // operands — supplies the IEEE results for n = +-0, inf, NaN and a = 0 (inf / NaN), bit for bit what the
 // division gives.  The test reads the exponents (v_frexp_exp_i32_f32: 0 for zero, inf and NaN) so that an
@@ -104,28 +104,36 @@ __device__ __forceinline__ DivPairs div_pairs(uint32_t m, const FLUID_LDS char* 
     d.c[3] = lds_ld2(table, m8 >> 24);
     return d;
 }
-// the four quotients of a lane: n / aii, aii = bytes of m, (aii, RN(1 / aii)) = d
+// the four quotients of a lane: n / aii, aii = bytes of m, (aii, RN(1 / aii)) = d.
+// ZEROS_QUICK: exact zeros do not count as tiny (the exponents are read when the cheap look fires).  The
+// kernels of wide grids (NT >= 2), whose launches are bound by bandwidth, are built that way — a full 512^3
+// tank runs 13 % faster for it; those of one x tile (grids up to 256 cells wide, x-window launches on a small
+// box of water) run launches bound by latency, where the longer code costs 4-7 % whether or not it is taken
+// (tools/ab_libs.py at 128^3 and 256^3), and keep the plain test: wavefronts with a zero take the IEEE
+// sequence there, as exact as the other.
+template <bool ZEROS_QUICK>
 __device__ __forceinline__ float4 canon_div4(float4 n, uint32_t m, const DivPairs& d) {
-    // two steps, both wave-uniform: the cheap look (three v_min with |.|) finds zeros too; only then the exponents
-    const float least = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
-    bool ieee = false;
-    if (__builtin_amdgcn_ballot_w64(least < 0x1p-100f) != 0ull) {
-        const int ex = min(min(__builtin_amdgcn_frexp_expf(n.x), __builtin_amdgcn_frexp_expf(n.y)),
-                           min(__builtin_amdgcn_frexp_expf(n.z), __builtin_amdgcn_frexp_expf(n.w)));
-        ieee = __builtin_amdgcn_ballot_w64(ex < -99) != 0ull;  // some 0 < |n| < 2^-100 in this wavefront
-    }
-    float4 o;
-    if (!ieee) {
+    auto quick = [&]() {
+        float4 o;
         o.x = div_small_int(n.x, d.c[0]);
         o.y = div_small_int(n.y, d.c[1]);
         o.z = div_small_int(n.z, d.c[2]);
         o.w = div_small_int(n.w, d.c[3]);
-    } else {
-        o.x = n.x / (float)(m & 0xFFu);
-        o.y = n.y / (float)((m >> 8) & 0xFFu);
-        o.z = n.z / (float)((m >> 16) & 0xFFu);
-        o.w = n.w / (float)(m >> 24);
+        return o;
+    };
+    // wave-uniform: one cheap look (three v_min with |.|) and one branch in the common case
+    const float least = fminf(fminf(fabsf(n.x), fabsf(n.y)), fminf(fabsf(n.z), fabsf(n.w)));
+    if (__builtin_amdgcn_ballot_w64(least < 0x1p-100f) == 0ull) return quick();
+    if (ZEROS_QUICK) {
+        const int ex = min(min(__builtin_amdgcn_frexp_expf(n.x), __builtin_amdgcn_frexp_expf(n.y)),
+                           min(__builtin_amdgcn_frexp_expf(n.z), __builtin_amdgcn_frexp_expf(n.w)));
+        if (__builtin_amdgcn_ballot_w64(ex < -99) == 0ull) return quick();  // only zeros were small
     }
+    float4 o;  // some |n| < 2^-100 in this wavefront: the IEEE sequence for all its lanes
+    o.x = n.x / (float)(m & 0xFFu);
+    o.y = n.y / (float)((m >> 8) & 0xFFu);
+    o.z = n.z / (float)((m >> 16) & 0xFFu);
+    o.w = n.w / (float)(m >> 24);
     return o;
 }
 
@@ -281,7 +289,7 @@ struct FusedCtx {
 // SOR (the opt-in red-black solver, fluid_set_pressure_solver): the quotient is the Gauss-Seidel value gs and
 // only the cells of the stage's colour move, c + omega * (gs - c) (oracle_12_sor_iteration's operations);
 // a lane's cells 0, 2 have one colour and 1, 3 the other: `odd` = the stage's colour sits on cells 1, 3.
-template <bool SOR>
+template <bool SOR, bool ZEROS_QUICK>
 __device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, float4 yp, float4 zp,
                                              float4 ym, float4 zm, float left, float right,
                                              const DivPairs& d, float omega = 0.f, bool odd = false) {
@@ -290,7 +298,7 @@ __device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, flo
     n.y = canon_num(b.y, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
     n.z = canon_num(b.z, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
     n.w = canon_num(b.w, right, yp.w, zp.w, c.z, ym.w, zm.w);
-    float4 o = canon_div4(n, m, d);
+    float4 o = canon_div4<ZEROS_QUICK>(n, m, d);
     if (SOR) {
         o.x = c.x + omega * (o.x - c.x);
         o.y = c.y + omega * (o.y - c.y);
@@ -398,7 +406,7 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
             const float left = from_lane_below(jc.w, je[i], c.lane);
             const float right = from_lane_above(jc.x, je[i], c.lane);
             // SOR: stage 1 moves the cells with (x + y + z) even; x of a lane's cell 0 is a multiple of 4
-            row[i].s[SC] = canon_lane<SOR>(row[i].b[BC], m_c[i], jc, yp, row[i].j[JN], ym, row[i].j[JM], left,
+            row[i].s[SC] = canon_lane<SOR, (NT >= 2)>(row[i].b[BC], m_c[i], jc, yp, row[i].j[JN], ym, row[i].j[JM], left,
                                            right, d1[i], c.omega, ((row[i].y + c.gz0 + zc) & 1) != 0);
         }
     }
@@ -433,7 +441,7 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
             const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].s[SM] : sext_hi;
             const float left = from_lane_below(sm.w, se[i], c.lane);
             const float right = from_lane_above(sm.x, se[i], c.lane);
-            o[i] = canon_lane<SOR>(row[i].b[BM], row[i].m[BM], sm, yp, row[i].s[SC], ym, row[i].s[SMM], left,
+            o[i] = canon_lane<SOR, (NT >= 2)>(row[i].b[BM], row[i].m[BM], sm, yp, row[i].s[SC], ym, row[i].s[SMM], left,
                                    right, d2[i], c.omega, ((row[i].y + c.gz0 + zo) & 1) == 0);  // stage 2: odd cells
         }
     }
