@@ -653,12 +653,12 @@ def test_pressure_division_special_values(iters, tiny):
     assert np.isnan(got).any() and np.isinf(got).any() and (got == 0).any()
 
 
-@pytest.mark.parametrize("quiet", [0, 1, 2])
-def test_full_step_quiet_bricks_match_oracle(quiet):
+@pytest.mark.parametrize("quiet,size", [(0, (64, 64, 96)), (1, (64, 64, 96)), (2, (64, 64, 96)),
+                                        (2, (64, 62, 88))])   # brick layers cut by the grid: 88 = 5.5 x 16, 62 = 15.5 x 4
+def test_full_step_quiet_bricks_match_oracle(quiet, size):
     """Ten dam-break steps on a grid with room around the water: from the third step on fluid_run_step
     skips the bricks far from the water in 07+08, 09+10+11 and 13 (quiet_bricks.h).  Every image equals
     the oracle's after every step; the same with the skipping turned off."""
-    size = (64, 64, 96)
     p, cap = dam_break_params(*size)
     iters = 6
     st = OracleState(p, cap, iters)
