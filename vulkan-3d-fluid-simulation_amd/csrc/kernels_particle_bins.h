@@ -67,6 +67,39 @@ __device__ __forceinline__ int psort_insert(uint32_t* keys, uint32_t key) {
     }
     return -1;
 }
+// The lanes of a wavefront mostly hold particles of the same bin (the storage is sorted already, or in spawn
+// order): one lane per distinct key does the table work for all of them.  Peels the wavefront key by key
+// (`active`: lanes that take part); returns this lane's table entry (or -1), its rank among the lanes of
+// its key and their number.  leader = the lane that should add `peers` to the entry's count.
+struct WaveKey {
+    int entry;
+    uint32_t rank, peers;
+    bool leader;
+};
+__device__ __forceinline__ WaveKey psort_wave_insert(uint32_t* keys, uint32_t key, bool active) {
+    WaveKey r;
+    r.entry = -1;
+    r.rank = r.peers = 0u;
+    r.leader = false;
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    while (todo) {  // wave-uniform
+        const int first = __builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(active && key == k0) & todo;
+        int e = 0;
+        if (lane == first) e = psort_insert(keys, k0);
+        e = __builtin_amdgcn_readlane(e, first);
+        if ((same >> lane) & 1ull) {
+            r.entry = e;
+            r.rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            r.peers = (uint32_t)__builtin_popcountll(same);
+            r.leader = lane == first;
+        }
+        todo &= ~same;
+    }
+    return r;
+}
 
 // pass 1: particles per bin
 __global__ void __launch_bounds__(PSORT_THREADS)
@@ -83,13 +116,15 @@ k_pbin_histogram(const float4* __restrict__ particles, uint64_t capacity, GridK 
 #pragma unroll 4
     for (int k = 0; k < PSORT_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
-        if (i >= capacity) break;
-        const uint32_t key = particle_bin(particles[i], g, p, b);
-        const int e = psort_insert(keys, key);
-        if (e >= 0)
-            atomicAdd(&counts[e], 1u);
-        else
-            atomicAdd(&bin_count[key], 1u);
+        const bool in = i < capacity;
+        const uint32_t key = in ? particle_bin(particles[i], g, p, b) : 0u;
+        const WaveKey w = psort_wave_insert(keys, key, in);
+        if (w.leader) {
+            if (w.entry >= 0)
+                atomicAdd(&counts[w.entry], w.peers);
+            else
+                atomicAdd(&bin_count[key], w.peers);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS)
@@ -138,17 +173,29 @@ k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict_
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * (PSORT_THREADS * PSORT_PER_THREAD);
     float4 q[PSORT_PER_THREAD];
-    int entry[PSORT_PER_THREAD];      // table entry, or -1: `rank` is the final position already
+    int entry[PSORT_PER_THREAD];      // table entry, -1: `rank` is the final position already, -2: no particle
     uint32_t rank[PSORT_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PSORT_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
-        entry[k] = -2;
-        if (i >= capacity) continue;
-        q[k] = particles[i];
-        const uint32_t key = particle_bin(q[k], g, p, b);
-        entry[k] = psort_insert(keys, key);
-        rank[k] = entry[k] >= 0 ? atomicAdd(&counts[entry[k]], 1u) : atomicAdd(&cursor[key], 1u);
+        const bool in = i < capacity;
+        q[k] = in ? particles[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t key = in ? particle_bin(q[k], g, p, b) : 0u;
+        const WaveKey w = psort_wave_insert(keys, key, in);
+        // one reservation per wavefront and key: the leader's old count is where its lanes start
+        uint32_t first = 0u;
+        if (w.leader) first = w.entry >= 0 ? atomicAdd(&counts[w.entry], w.peers) : atomicAdd(&cursor[key], w.peers);
+        const unsigned long long leaders = __builtin_amdgcn_ballot_w64(w.leader);
+        // every lane reads its leader's `first`: the leader is the lowest lane of its key
+        uint32_t mine = 0u;
+        for (unsigned long long l = leaders; l; l &= l - 1) {  // wave-uniform: one round per distinct key
+            const int ll = __builtin_ctzll(l);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)first, ll);
+            const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, ll);
+            if (in && key == kk) mine = f;
+        }
+        entry[k] = in ? w.entry : -2;
+        rank[k] = mine + w.rank;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS)
