@@ -1203,9 +1203,18 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k07_advect<true>, qgrid, block, 0, c->stream, T, V1, V2, gqh, pk,
                                    c->flags(), c->quiet_or_null(), bk, qchunks);
             else
-                hipLaunchKernelGGL(k07_advect_tiled<true>, dim3(qgrid.x, qgrid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
+            {
+                // A workgroup marches a brick layer of ONE 64-cell chunk of a row: with all four chunks of the
+                // brick row in one workgroup (as the other skipping passes have it) a sparse scene's launch lasts
+                // as long as 64 plane steps in a row take (0.41 ms at 512^3); four times the workgroups cost 10 us
+                // of dispatch.  FLUID_ADVECT_XCHUNKS (dev) overrides.
+                static const int forced = getenv("FLUID_ADVECT_XCHUNKS") ? atoi(getenv("FLUID_ADVECT_XCHUNKS")) : 0;
+                const int xch = forced > 0 ? forced : 1;
+                hipLaunchKernelGGL(k07_advect_tiled<true>,
+                                   dim3((g.W + 64 * xch - 1) / (64 * xch), grid.y, (g.Dl + K07_ZM - 1) / K07_ZM),
                                    block, 0, c->stream, T, V1, V2, g, pk, c->flags(), c->quiet_or_null(), bk,
-                                   qchunks, c->quiet_in_use ? c->bricks() : (const uint8_t*)nullptr);
+                                   xch, c->quiet_in_use ? c->bricks() : (const uint8_t*)nullptr);
+            }
             break;
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);

@@ -322,8 +322,9 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
     // its +x / +y / +z neighbour is water (advect.comp:65-68) and takes a force if it or the cell below it is
     // water (forces.comp:39-49): with no water in this workgroup's brick nor in the bricks beyond its +x, +y,
     // +z and -y faces the pass is a copy with w = 0.  A brick layer of a neighbouring slab counts as wet.
-    if (active && xchunks == BRICK_X / 64) {
-        const int bx = (int)blockIdx.x, by = (int)(blockIdx.y * 4u) / BRICK_Y, bz = (int)blockIdx.z;
+    if (active) {
+        const int bx = (int)(blockIdx.x * 64u * (unsigned)xchunks) / BRICK_X, by = (int)(blockIdx.y * 4u) / BRICK_Y,
+                  bz = (int)blockIdx.z;
         uint32_t any = active[brick_index(bk, bx, by, bz)];
         if (bx + 1 < bk.nbx) any |= active[brick_index(bk, bx + 1, by, bz)];
         if (by + 1 < bk.nby) any |= active[brick_index(bk, bx, by + 1, bz)];
