@@ -116,6 +116,7 @@ def _check(got, world, size, iters, steps, intended=False, fast=0.0):
     (2, (32, 24, 16), 12, 4, False, False),  # the section list, one kernel per section
     (2, (30, 24, 16), 12, 4, True, False),   # width not a multiple of 4
     (2, (32, 24, 16), 12, 4, True, True),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
+    (3, (64, 32, 48), 8, 60, True, False),  # a long run: the block collapses across both faces and spreads
 ])
 def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
     import torch.multiprocessing as mp
