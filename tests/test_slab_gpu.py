@@ -280,3 +280,33 @@ def test_c5_slab_1024x1024x64_equals_the_whole_grid_run_and_an_oracle_window():
     lo, hi = iters, zc - iters
     assert_bit_equal(got[E.PRESSURES_1][4 + lo:4 + hi], sw.pressures_1[lo:hi], "C5 slab window P1")
     assert_bit_equal(got[E.PRESSURES_2][4 + lo:4 + hi], sw.pressures_2[lo:hi], "C5 slab window P2")
+
+
+def test_cpp_slab_host_program_one_rank_matches_oracle(tmp_path):
+    """host/fluid_sim_slab.cpp, the program a maintainer starts once per GPU (the reference's main.cpp loop over
+    include/fluid_slab.h), as the only rank of a run: its dumped images and particles equal the oracle's after
+    the same frames.  (More ranks need more GPUs: the driver's schedule is what the gloo and one-GPU tests of
+    this directory pin, the RCCL calls what the communicator-of-one rehearsals do.)"""
+    import subprocess
+
+    from fluid_amd.params import dam_break_params
+    from helpers import assert_bit_equal
+    from oracle_binding import OracleState
+
+    exe = os.path.join(ROOT, "vulkan-3d-fluid-simulation_amd", "host", "fluid_sim_slab")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    size, frames, iters = (32, 32, 32), 3, 10
+    res = subprocess.run([exe, "0", "1", str(tmp_path / "id"), *map(str, size), str(frames), str(iters),
+                          str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rank 0 ok" in res.stdout
+    p, cap = dam_break_params(*size)
+    st = OracleState(p, cap, iters)
+    st.run_init()
+    for _ in range(frames):
+        st.run_step()
+    for name, dtype in [("velocities_1", np.float32), ("cell_types", np.uint8), ("pressures_1", np.float32),
+                        ("pressures_2", np.float32), ("particles", np.float32)]:
+        got = np.fromfile(os.path.join(str(tmp_path), name + ".0.bin"), dtype=dtype)
+        assert_bit_equal(got.reshape(getattr(st, name).shape), getattr(st, name), f"fluid_sim_slab {name}")
