@@ -304,8 +304,11 @@ struct WgOr {
         return *w;
     }
 };
+// Four wavefronts per SIMD: left alone hipcc takes 137 VGPRs (three); held to 128 it spills 24 bytes per lane and
+// the full 512^3 tank's pass drops from 4.6 to 3.9 ms; held to 96 (five, which the LDS would allow) it spills
+// 150 and is back at 4.7.
 template <bool FORCES>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                  float4* __restrict__ v2, GridK g, ParamsK p, uint32_t* __restrict__ violation,
                  const uint8_t* __restrict__ quiet, BrickK bk, int xchunks,
