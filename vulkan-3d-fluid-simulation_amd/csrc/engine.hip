@@ -969,7 +969,9 @@ int psort_sort(fluid_ctx* c) {
                        ps.bk, ps.bin_count);
     hipLaunchKernelGGL(k_pbin_scan, dim3(1), dim3(1024), 0, c->stream, ps.bin_count, ps.bk.bins + 1,
                        ps.bin_start, ps.cursor);
-    hipLaunchKernelGGL(k_pbin_scatter, dim3(blocks), dim3(PSORT_THREADS), 0, c->stream, in, slot_in, n, c->g,
+    const uint64_t per_block2 = (uint64_t)PSORT_THREADS * PSCATTER_PER_THREAD;
+    hipLaunchKernelGGL(k_pbin_scatter, dim3((unsigned)((n + per_block2 - 1) / per_block2)), dim3(PSORT_THREADS), 0,
+                       c->stream, in, slot_in, n, c->g,
                        c->pk, ps.bk, ps.cursor, out, ps.slot_of[dst]);
     HIP_TRY(c, hipGetLastError());
     ps.cur = dst;

@@ -158,6 +158,8 @@ k_pbin_scan(const uint32_t* __restrict__ bin_count, uint32_t n, uint32_t* __rest
     if (threadIdx.x == 1023) bin_start[n] = part[1023];
 }
 
+// (eight particles per thread here: the sixteen of pass 1 held in registers leave three wavefronts per SIMD)
+constexpr int PSCATTER_PER_THREAD = 8;
 // pass 2: every particle to its bin's segment of `out`, its slot with it.  slot_in == nullptr: the input
 // is in slot order.
 __global__ void __launch_bounds__(PSORT_THREADS)
@@ -171,12 +173,12 @@ k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict_
         counts[i] = 0u;
     }
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * (PSORT_THREADS * PSORT_PER_THREAD);
-    float4 q[PSORT_PER_THREAD];
-    int entry[PSORT_PER_THREAD];      // table entry, -1: `rank` is the final position already, -2: no particle
-    uint32_t rank[PSORT_PER_THREAD];
+    const uint64_t base = (uint64_t)blockIdx.x * (PSORT_THREADS * PSCATTER_PER_THREAD);
+    float4 q[PSCATTER_PER_THREAD];
+    int entry[PSCATTER_PER_THREAD];      // table entry, -1: `rank` is the final position already, -2: no particle
+    uint32_t rank[PSCATTER_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < PSORT_PER_THREAD; k++) {
+    for (int k = 0; k < PSCATTER_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
         const bool in = i < capacity;
         q[k] = in ? particles[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,7 +204,7 @@ k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict_
         if (keys[i] != PSORT_EMPTY) counts[i] = atomicAdd(&cursor[keys[i]], counts[i]);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PSORT_PER_THREAD; k++) {
+    for (int k = 0; k < PSCATTER_PER_THREAD; k++) {
         if (entry[k] == -2) continue;
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
         const uint32_t dst = entry[k] >= 0 ? counts[entry[k]] + rank[k] : rank[k];
