@@ -290,9 +290,10 @@ __global__ void k12_sor_colour_v4(const uint8_t* __restrict__ t, const float* __
     const uint32_t tzp = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz + 1));
     const uint32_t tzm = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz - 1));
     const uint32_t tl = x > 0 ? (uint32_t)t[id - 1] : 0u, tr = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     auto prow = [&](int ny) {
-        return (unsigned)ny < (unsigned)g.H ? *reinterpret_cast<const float4*>(pr + cidx(g, x, ny, lz)) : zero;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ny < (unsigned)g.H) v = *reinterpret_cast<const float4*>(pr + cidx(g, x, ny, lz));
+        return v;
     };
     const float4 pc = *reinterpret_cast<const float4*>(pr + id);
     const float4 pyp = prow(y + 1), pym = prow(y - 1);

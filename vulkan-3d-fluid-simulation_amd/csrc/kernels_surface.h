@@ -136,11 +136,12 @@ __global__ void k16_detailed_densities_inertia_v4(const uint32_t* __restrict__ d
                                                   float* __restrict__ f1, SurfK s, InertiaK k,
                                                   float coefficient) {
     FLUID_SURF4_THREAD();
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    // (a select between a loaded vector and a named zero constant makes hipcc keep the constant in scratch)
     auto row = [&](int ny, int nz) {
-        return ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
-                   ? *reinterpret_cast<const uint4*>(detailed + sidx(s, x, ny, nz))
-                   : zero;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
+            v = *reinterpret_cast<const uint4*>(detailed + sidx(s, x, ny, nz));
+        return v;
     };
     const uint4 c = *reinterpret_cast<const uint4*>(detailed + id);
     const uint4 yp = row(y + 1, z), ym = row(y - 1, z), zp = row(y, z + 1), zm = row(y, z - 1);
@@ -187,11 +188,11 @@ __global__ void k18_diffuse_float_densities_v4(const uint8_t* __restrict__ types
                                                const float* __restrict__ src, float* __restrict__ dst,
                                                SurfK s, float a, uint32_t t_solid) {
     FLUID_SURF4_THREAD();
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     auto row = [&](int ny, int nz) {
-        return ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
-                   ? *reinterpret_cast<const float4*>(src + sidx(s, x, ny, nz))
-                   : zero;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ny < (unsigned)s.H && (unsigned)nz < (unsigned)s.D)
+            v = *reinterpret_cast<const float4*>(src + sidx(s, x, ny, nz));
+        return v;
     };
     const float4 c = *reinterpret_cast<const float4*>(src + id);
     const float4 yp = row(y + 1, z), ym = row(y - 1, z), zp = row(y, z + 1), zm = row(y, z - 1);
@@ -215,7 +216,7 @@ __global__ void k18_diffuse_float_densities_v4(const uint8_t* __restrict__ types
         }
     }
     // cells of SOLID simulation cells are not written: they keep what the destination holds
-    float4 old = zero;
+    float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
     if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
     float out[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
@@ -255,13 +256,12 @@ k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const floa
     const int y = blockIdx.y * K18_ROWS + ty;
     const bool valid = x < s.W && y < s.H;  // invalid threads still take part in the barriers
     const int zb = blockIdx.z * zchunk, ze = min(zb + zchunk, s.D);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const float k0 = 1.0f - 6.0f * a;
     const int64_t rowoff = (int64_t)x + (int64_t)s.W * (int64_t)y;
     auto plane_ld = [&](int z) {
-        return (valid && (unsigned)z < (unsigned)s.D)
-                   ? *reinterpret_cast<const float4*>(src + rowoff + s.plane * z)
-                   : zero;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && (unsigned)z < (unsigned)s.D) v = *reinterpret_cast<const float4*>(src + rowoff + s.plane * z);
+        return v;
     };
     // halo rows of the tile: the first / last thread row also loads the row below / above the tile
     const bool halo_row = ty == 0 || ty == K18_ROWS - 1;
@@ -283,7 +283,8 @@ k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const floa
         float* row = &tile[buf][ty + 1][K18_PAD + 4 * tx];
         *reinterpret_cast<float4*>(row) = c;
         if (halo_row) {
-            const float4 h = halo_in ? *reinterpret_cast<const float4*>(src + halo_off + s.plane * z) : zero;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (halo_in) h = *reinterpret_cast<const float4*>(src + halo_off + s.plane * z);
             *reinterpret_cast<float4*>(&tile[buf][ty == 0 ? 0 : K18_ROWS + 1][K18_PAD + 4 * tx]) = h;
         }
         if (edge) row[tx == 0 ? -1 : 4] = edge_in ? src[id + (tx == 0 ? -1 : 4)] : 0.0f;
@@ -306,7 +307,7 @@ k18_diffuse_float_densities_zmarch(const uint8_t* __restrict__ types, const floa
                     cx++;
                 }
             }
-            float4 old = zero;
+            float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
             if (any_solid) old = *reinterpret_cast<const float4*>(dst + id);
             const float cc[4] = {c.x, c.y, c.z, c.w};
             const float a_yp[4] = {yp.x, yp.y, yp.z, yp.w}, a_ym[4] = {ym.x, ym.y, ym.z, ym.w};
