@@ -71,9 +71,11 @@ static inline int cu_count() {
 
 // rows per wavefront (FusedGeom) by x tiles per row, measured on MI355X (Jacobi iterations/s, RG = 1 / 2 / 3):
 //   NT = 1 (256^3)          27.3 k / 24.6 k / 43.7 k    R = 16 / 16 / 24 rows per workgroup
-//   NT = 2 (512^3)          5.60 k / 5.61 k / 5.22 k    R =  8 /  8 / 12 (RG = 3 spills at NT >= 2)
+//   NT = 2 (512^3)          5.09 k / 5.58 k / 5.76 k    R =  8 /  8 / 12 (225 VGPRs, no spill since the plane
+//                                                       step was reordered; before that: 5.60 / 5.61 / 5.22)
 //   NT = 4 (1024 x 1024 x 64)  9.3 k / 8.7 k / 11.9 k   R =  4 /  4 /  6: the halo rows are half / a third
-// FLUID_FUSED_RG = 1, 2 or 3 overrides it.
+// Three rows everywhere, then: also the 512 x 512 x 64 slab of an 8-way run (+ 10 %) and the loop inside a
+// full-tank step (37.0 -> 35.4 ms).  FLUID_FUSED_RG = 1, 2 or 3 overrides it.
 static inline int fused_rows_per_wave(int nt) {
     static const int forced = [] {
         const char* e = getenv("FLUID_FUSED_RG");
@@ -81,7 +83,8 @@ static inline int fused_rows_per_wave(int nt) {
         return (v >= 1 && v <= 3) ? v : 0;
     }();
     if (forced) return forced;
-    return nt == 2 ? 2 : 3;
+    (void)nt;
+    return 3;
 }
 
 template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false>
@@ -159,12 +162,12 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     // placement is an observed property of the dispatcher, used for speed only; FLUID_FUSED_XCD=0 turns it
     // off.
     r.xcd_rows = r.xcd_nz = 0;
-    static const bool xcd_bands = [] {
+    static const int xcd_bands = [] {  // 0 = off, 1 = where they come out even (default), 2 = always (tuning)
         const char* e = getenv("FLUID_FUSED_XCD");
-        return e == nullptr || atoi(e) != 0;
+        return e == nullptr ? 1 : atoi(e);
     }();
     // only where the bands come out even: the longest band sets the time (by / 8 row tiles each, rounded up)
-    if (xcd_bands && by >= 8 && 8 * ((by + 7) / 8) * 100 <= by * 104) {
+    if (xcd_bands && by >= 8 && (xcd_bands == 2 || 8 * ((by + 7) / 8) * 100 <= by * 104)) {
         r.xcd_rows = by;
         r.xcd_nz = nz;
         grid = dim3(8 * ((by + 7) / 8) * nz, 1, 1);
