@@ -263,17 +263,18 @@ def full_step_bench(size, iters, steps, device):
     }
 
 
-def full_step_dense_bench(n, iters, steps, device):
+def full_step_dense_bench(grid, iters, steps, device):
     """Full simulation steps/sec (01a...14) on a tank filled to the brim: every section works on nearly
     every cell and nothing is skipped, so the algorithmic bytes of SURVEY.md 8d (reference layout:
     293 + 13 x iterations B/cell, 48 B/particle) over the step time IS a roofline statement."""
     import fluid_amd
     from fluid_amd import engine as E
 
-    size = (n - 4.0,) * 3
+    w, h, d = grid
+    size = (w - 4.0, h - 4.0, d - 4.0)
     res = tuple(int(round(2.0 * v)) for v in size)
     cap = res[0] * res[1] * res[2]
-    p = fluid_amd.default_params(n, n, n, cap)
+    p = fluid_amd.default_params(w, h, d, cap)
     p.particle_spawn_cube_resolution[:] = res
     p.particle_spawn_cube_volume = cap
     p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
@@ -295,9 +296,10 @@ def full_step_dense_bench(n, iters, steps, device):
             eng.run_step()
         eng.sync()
         sections = {k: round(v[0] / 2, 4) for k, v in eng.section_times().items() if v[1]}
-    cells = n ** 3
+    cells = w * h * d
     step_bytes = (293.0 + 13.0 * iters) * cells + 48.0 * cap   # SURVEY.md 8d, reference layout
-    return {"workload": f"full tank {n}^3, {cap} particles (8 per cell), {iters} Jacobi iters",
+    shape = f"{w}^3" if w == h == d else f"{w}x{h}x{d}"
+    return {"workload": f"full tank {shape}, {cap} particles (8 per cell), {iters} Jacobi iters",
             "steps_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps,
             "algorithmic_bytes_per_step": step_bytes,
             "algorithmic_GBps": step_bytes / dt / 1e9,
@@ -558,7 +560,7 @@ def main():
     if not args.no_full_step:
         out["full_step"] = full_step_bench(size, args.iters, args.full_step_steps, local_rank)
         try:
-            out["full_step_dense"] = full_step_dense_bench(w, args.iters, 3, local_rank)
+            out["full_step_dense"] = full_step_dense_bench(size, args.iters, 3, local_rank)
         except Exception as exc:  # secondary figure (needs 16 B x 8 particles per cell of HBM)
             out["full_step_dense"] = {"error": f"{type(exc).__name__}: {exc}"}
     if not args.no_surface and not args.no_full_step:

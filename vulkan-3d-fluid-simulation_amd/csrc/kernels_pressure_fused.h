@@ -205,12 +205,14 @@ struct FusedGeom {
 //                       Valid when every water cell of the grid lies inside the window: the columns
 //                       just outside it then hold non-water constants, the same in every iterate, which
 //                       the edge lanes load into the pad cells of the LDS rows.
-//   xcd_rows, xcd_nz    > 0: the launch is a 1-D grid; workgroup L runs on XCD L % 8 (the dispatcher deals
-//                       workgroups to the 8 XCDs in turn) and takes tile L / 8 of that XCD's own list — a
-//                       band of row tiles x all z chunks — so that workgroups which share halo rows share
-//                       an L2.  xcd_rows = row tiles in the launch, xcd_nz = chunks.
+//   xcd_rows, xcd_start xcd_rows > 0: the launch is a 1-D grid; workgroup L runs on XCD L % 8 (the dispatcher
+//                       deals workgroups to the 8 XCDs in turn) and takes unit xcd_start[L % 8] + L / 8 of the
+//                       launch's (chunk, row tile) units, row tile first — a contiguous range per XCD, cut
+//                       by the host so that the ranges cost the same — so that workgroups which share halo
+//                       rows share an L2.  xcd_rows = row tiles in the launch.
 struct FusedRange {
-    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0, xcd_rows, xcd_nz;
+    int zout_lo, zout_hi, jlo, jhi, mlo, mhi, ytile0, hole_lo, hole_hi, nz_lo, xwin0, xcd_rows;
+    int xcd_start[9];
 };
 
 // State of one row of a wavefront during the z march.  Everything rotates with period 4 (the z loop is
@@ -518,15 +520,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     c.x0 = tx * 256 + c.lane * 4;
     int tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
     if (rg.xcd_rows > 0) {
+        // XCD `xcd` takes the units [xcd_start[xcd], xcd_start[xcd + 1]): the workgroups it runs side by side
+        // are y-neighbours of one chunk, whose shared halo rows its L2 then serves
         const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
-        // band of XCD `xcd`: rows [r0, r0 + nr) of the launch's row tiles (the first xcd_rows % 8 bands get
-        // one more)
-        const int base = rg.xcd_rows >> 3, extra = rg.xcd_rows & 7;
-        const int nr = base + (xcd < extra ? 1 : 0);
-        const int r0 = xcd * base + min(xcd, extra);
-        if (slot >= nr * rg.xcd_nz) return;  // padding of the shorter lists (uniform)
-        tile_z = slot / nr;
-        tile_y = r0 + slot - tile_z * nr;
+        const int u = rg.xcd_start[xcd] + slot;
+        if (u >= rg.xcd_start[xcd + 1]) return;  // padding of the shorter lists (uniform)
+        tile_z = u / rg.xcd_rows;
+        tile_y = u - tile_z * rg.xcd_rows;
     }
     const int y0 = (tile_y + rg.ytile0) * TY;  // first output row
     if (tile_z < rg.nz_lo) {

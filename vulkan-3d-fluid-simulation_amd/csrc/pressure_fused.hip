@@ -22,7 +22,7 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
     rg.hole_lo = rg.hole_hi = rg.zout_hi;
     rg.nz_lo = 0;
     rg.xwin0 = 0;
-    rg.xcd_rows = rg.xcd_nz = 0;
+    rg.xcd_rows = 0;
     const int nt = (g.W + 255) / 256;
     // Sparse scene: if the bricks that hold water (on a Z slab: here and in the neighbouring slabs) span one or two 256-cell columns of
     // a wider grid, launch over that x window only (fewer lanes, more rows per workgroup).
@@ -63,7 +63,7 @@ hipError_t k12_launch_canon2_sor(hipStream_t s, const uint8_t* mask, const float
     rg.hole_lo = rg.hole_hi = rg.zout_hi;
     rg.nz_lo = 0;
     rg.xwin0 = 0;
-    rg.xcd_rows = rg.xcd_nz = 0;
+    rg.xcd_rows = 0;
     const int nt = (g.W + 255) / 256;
     // the instantiations the Jacobi loop defaults to for full rows (pressure_fused_launch.h)
     if (nt == 1)

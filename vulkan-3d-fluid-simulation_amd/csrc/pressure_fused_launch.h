@@ -7,6 +7,7 @@
 #include "pressure_api.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -55,6 +56,75 @@ static inline int pick_zchunk(int row_groups, int depth, int cus) {
     }
     cache[key] = best;
     return best;
+}
+
+// Ranges of a launch's (chunk, row tile) units for the 8 XCDs (FusedRange::xcd_start), or none.  Two
+// candidates — the same number of units each, the same cost each (the last chunk of a segment is shorter:
+// pick_zchunk fills the last round of workgroups with it) — and the dispatcher's own deal (unit L to XCD
+// L % 8) are run through the makespan model XCD by XCD; the better candidate is used unless the deal beats it
+// by more than 6 %.
+// Measured (profiles/round02/xcd_ranges_ab.txt): 256^3, 240 units of one round: ranges of 30 units 41 us,
+// the deal 45 us, ranges of 29..32 units 59 us — the XCD handed 32 workgroups for its 32 CUs ran a second
+// round, so a launch of one round is modelled on one CU fewer per XCD; 512^3, 520 units: equal counts give one
+// XCD 65 full-length units, three rounds where the deal and equal costs run two; 1024 x 1024 x 64, 256 units:
+// ranges 167 us, the deal 183 us.
+struct XcdPlan {
+    bool on;
+    int start[9];
+};
+static inline XcdPlan xcd_plan(int by, int nz_lo, int nz, int zchunk, int seg1, int seg2, int cus) {
+    static std::map<std::tuple<int, int, int, int, int, int, int>, XcdPlan> cache;
+    static std::mutex cache_mutex;
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    const auto key = std::make_tuple(by, nz_lo, nz, zchunk, seg1, seg2, cus);
+    const auto hit = cache.find(key);
+    if (hit != cache.end()) return hit->second;
+    const int U = by * nz;
+    std::vector<int> cost(U);
+    long total = 0;
+    for (int tz = 0, u = 0; tz < nz; tz++) {
+        const int planes = tz < nz_lo ? std::min(zchunk, seg1 - tz * zchunk)
+                                      : std::min(zchunk, seg2 - (tz - nz_lo) * zchunk);
+        for (int y = 0; y < by; y++, u++) total += cost[u] = planes + 5;  // pick_zchunk's cost of a workgroup
+    }
+    auto makespan = [&](int u0, int u1, int step, int n_cus) {  // in-order list scheduling, as in pick_zchunk
+        std::vector<long> busy(std::max(1, n_cus), 0);
+        auto cmp = [](long a, long b) { return a > b; };
+        long worst = 0;
+        for (int u = u0; u < u1; u += step) {
+            std::pop_heap(busy.begin(), busy.end(), cmp);
+            busy.back() += cost[u];
+            worst = std::max(worst, busy.back());
+            std::push_heap(busy.begin(), busy.end(), cmp);
+        }
+        return worst;
+    };
+    XcdPlan by_count, by_cost;
+    for (int x = 0; x <= 8; x++) by_count.start[x] = (int)((long)x * U / 8);
+    {
+        int x = 1;
+        long acc = 0;  // cost of the units before u
+        by_cost.start[0] = 0;
+        for (int u = 0; u < U; acc += cost[u], u++)
+            while (x < 8 && 8 * (2 * acc + cost[u]) > 2 * x * total) by_cost.start[x++] = u;
+        while (x <= 8) by_cost.start[x++] = U;
+    }
+    const int per_xcd = std::max(1, cus / 8 - (U <= cus ? 1 : 0));
+    long t_count = 0, t_cost = 0, t_deal = 0;
+    for (int x = 0; x < 8; x++) {
+        t_count = std::max(t_count, makespan(by_count.start[x], by_count.start[x + 1], 1, per_xcd));
+        t_cost = std::max(t_cost, makespan(by_cost.start[x], by_cost.start[x + 1], 1, per_xcd));
+        t_deal = std::max(t_deal, makespan(x, U, 8, per_xcd));
+    }
+    XcdPlan plan = t_cost < t_count ? by_cost : by_count;
+    // (6 % of slack: the model does not see the fabric reads the ranges save; 512^3 runs 126 against 120
+    // in the model and the same 0.347 ms on the GPU, with 1.35 instead of 1.69 GB read)
+    plan.on = 100 * std::min(t_cost, t_count) <= 106 * t_deal;
+    if (getenv("FLUID_FUSED_DEBUG"))  // one line per launch shape
+        fprintf(stderr, "xcd_plan: %d row tiles x %d chunks of %d planes: by count %ld, by cost %ld, dealt %ld -> %s\n",
+                by, nz, zchunk, t_count, t_cost, t_deal, plan.on ? (t_cost < t_count ? "by cost" : "by count") : "off");
+    cache[key] = plan;
+    return plan;
 }
 
 static inline int cu_count() {
@@ -156,21 +226,26 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     r.nz_lo = (seg1 + zchunk - 1) / zchunk;
     const int nz = r.nz_lo + (seg2 + zchunk - 1) / zchunk;
     dim3 grid(1, by, nz);
-    // Deal the row tiles to the XCDs in bands (workgroup L runs on XCD L % 8 and takes tile L / 8 of that
-    // XCD's list): y-adjacent workgroups then share an L2, which serves the halo rows they both read.
-    // Fabric reads of a 512^3 launch: 1.91 -> 1.35 GB (TCC_EA0_RDREQ x 128 B, profiles/round02).  The
-    // placement is an observed property of the dispatcher, used for speed only; FLUID_FUSED_XCD=0 turns it
-    // off.
-    r.xcd_rows = r.xcd_nz = 0;
-    static const int xcd_bands = [] {  // 0 = off, 1 = where they come out even (default), 2 = always (tuning)
+    // Deal the launch's units (chunk, row tile) to the XCDs in contiguous ranges (workgroup L runs on XCD
+    // L % 8 and takes unit L / 8 of that XCD's range): y-adjacent workgroups then share an L2, which serves
+    // the halo rows they both read.  Fabric reads of a 512^3 launch: 1.91 -> 1.35 GB (TCC_EA0_RDREQ x 128 B,
+    // profiles/round02).  The placement is an observed property of the dispatcher, used for speed only;
+    // FLUID_FUSED_XCD=0 turns it off, 2 uses the ranges whatever the model says of them.
+    r.xcd_rows = 0;
+    for (int& v : r.xcd_start) v = 0;
+    static const int xcd_ranges = [] {
         const char* e = getenv("FLUID_FUSED_XCD");
         return e == nullptr ? 1 : atoi(e);
     }();
-    // only where the bands come out even: the longest band sets the time (by / 8 row tiles each, rounded up)
-    if (xcd_bands && by >= 8 && (xcd_bands == 2 || 8 * ((by + 7) / 8) * 100 <= by * 104)) {
-        r.xcd_rows = by;
-        r.xcd_nz = nz;
-        grid = dim3(8 * ((by + 7) / 8) * nz, 1, 1);
+    if (xcd_ranges && by * nz >= 16) {
+        const XcdPlan plan = xcd_plan(by, r.nz_lo, nz, zchunk, seg1, seg2, cu_count());
+        if (plan.on || xcd_ranges == 2) {
+            int longest = 0;
+            for (int x = 0; x < 8; x++) longest = std::max(longest, plan.start[x + 1] - plan.start[x]);
+            for (int x = 0; x <= 8; x++) r.xcd_start[x] = plan.start[x];
+            r.xcd_rows = by;
+            grid = dim3(8 * longest, 1, 1);
+        }
     }
     BrickK bk;
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
