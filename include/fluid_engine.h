@@ -548,7 +548,10 @@ typedef enum fluid_option {
                                    /* order, so nothing is observable but the time.  0 = on from 4 M particle   */
                                    /* slots (default; needs 28 B per slot outside the arena, falls back to slot */
                                    /* order if that cannot be allocated), 1 = off, 2 = on at any size; 3 / 4 =   */
-                                   /* test modes (sort before every 01 / sort once and never again)             */
+                                   /* test modes (sort before every 01 / sort once and never again).            */
+                                   /* Z-slab contexts keep slot order and list the slots of the particles they  */
+                                   /* own instead (the buffer has a slot for every particle of every slab):     */
+                                   /* 1 = no list, every slot is read; any other value = list                   */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
@@ -588,8 +591,11 @@ typedef enum fluid_stat {
     FLUID_STAT_QUIET_BRICKS = 1, /* bricks the last fluid_run_step skipped in 07+08, 09+10+11 and 13   */
     FLUID_STAT_PARTICLE_SORTS = 2,   /* sorts of the particle storage so far (FLUID_OPT_PARTICLE_SORT)     */
     FLUID_STAT_PARTICLE_STRAYS = 3,  /* particles the last 01 found outside the bin they are stored in     */
-    FLUID_STAT_PARTICLE_BINNED = 4   /* 1 while 01 and 14 run on bins; 0 in slot order or while the flow    */
+    FLUID_STAT_PARTICLE_BINNED = 4,  /* 1 while 01 and 14 run on bins; 0 in slot order or while the flow    */
                                      /* moves the particles faster than sorting pays (tried again later)    */
+    FLUID_STAT_PARTICLE_ENTRIES = 5, /* entries 01, 14 and the search for leavers look at: every slot, or — */
+                                     /* Z-slab contexts — the entries of the list of particles the slab owns */
+    FLUID_STAT_OWNED_SQUEEZES = 6    /* times that list had its holes squeezed out                          */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 

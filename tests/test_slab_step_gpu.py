@@ -50,7 +50,7 @@ def drift(shape, fast=0.0):
     return v
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0, plain_slots=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -74,6 +74,10 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     sim.attach_torch_transport(device_memory=True)
     if world == 3:   # one workgroup per brick layer in the skipping passes, as on grids of >= 4096 bricks
         sim.engine.set_option(E.OPT_QUIET_BRICKS, 2)
+        # ... and the list of owned particles squeezed whenever it has a hole (by itself: from 65536 holes on)
+        sim.engine.set_option(E.OPT_PARTICLE_SORT, 3)
+    if plain_slots:  # no list of owned particles: 01, 14 and the search for leavers read every slot
+        sim.engine.set_option(E.OPT_PARTICLE_SORT, 1)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0]), fast))
@@ -84,7 +88,9 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
         ("pressures_1", E.PRESSURES_1), ("pressures_2", E.PRESSURES_2),
         ("divergences", E.DIVERGENCES), ("particle_densities", E.PARTICLE_DENSITIES_IMG)]}
     out["particles"] = sim.gather_particles()
-    t = torch.tensor([sim.stat(i) for i in range(8)] + [sim.engine.get_stat(E.STAT_QUIET_BRICKS)],
+    t = torch.tensor([sim.stat(i) for i in range(8)] + [sim.engine.get_stat(E.STAT_QUIET_BRICKS),
+                                                        sim.engine.get_stat(E.STAT_PARTICLE_ENTRIES),
+                                                        sim.engine.get_stat(E.STAT_OWNED_SQUEEZES)],
                      dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -111,22 +117,30 @@ def _check(got, world, size, iters, steps, intended=False, fast=0.0):
     return st
 
 
-@pytest.mark.parametrize("world,size,iters,steps,grouped,intended", [
-    (2, (32, 24, 16), 12, 6, True, False), (3, (64, 16, 24), 9, 5, True, False),
-    (2, (32, 24, 16), 12, 4, False, False),  # the section list, one kernel per section
-    (2, (30, 24, 16), 12, 4, True, False),   # width not a multiple of 4
-    (2, (32, 24, 16), 12, 4, True, True),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
-    (3, (64, 32, 48), 8, 60, True, False),  # a long run: the block collapses across both faces and spreads
+@pytest.mark.parametrize("world,size,iters,steps,grouped,intended,plain_slots", [
+    (2, (32, 24, 16), 12, 6, True, False, False), (3, (64, 16, 24), 9, 5, True, False, False),
+    (2, (32, 24, 16), 12, 4, False, False, False),  # the section list, one kernel per section
+    (2, (30, 24, 16), 12, 4, True, False, False),   # width not a multiple of 4
+    (2, (32, 24, 16), 12, 4, True, True, False),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
+    (3, (64, 32, 48), 8, 60, True, False, False),  # a long run: the block collapses across both faces and spreads
+    (2, (32, 24, 16), 12, 6, True, False, True),   # without the list of owned particles
 ])
-def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, tmp_path):
+def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, plain_slots, tmp_path):
     import torch.multiprocessing as mp
 
     from fluid_amd import slab as S
 
-    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended),
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, grouped, str(tmp_path), intended,
+                                      0.0, plain_slots),
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     st = _check(got, world, size, iters, steps, intended)
+    # 01, 14 and the search for leavers looked at the particles a slab owns, not at every slot of the buffer
+    _, cap = scene_params(size, intended)
+    entries, squeezes = int(got["stats"][9]), int(got["stats"][10])
+    assert entries == cap if plain_slots else 0 < entries < cap, (entries, cap)
+    if world == 3:
+        assert squeezes > 0
     # the scene did what the test is for: water on both sides of a face, particles changed owner
     d = size[2]
     face = d // world

@@ -1,0 +1,42 @@
+"""Dev tool: one rank of an N-way Z-slab run of the FULL TANK (8 particles per cell everywhere), neighbours
+played by itself (loopback), with the list of owned particles and without: what reading every slot of a
+particle buffer sized for all slabs costs 01 and 14 on each rank.
+    python tools/slab_dense_rank_step.py [grid=512] [ranks=8] [iters=200]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fluid_amd
+from fluid_amd import engine as E, slab as S
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+ranks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+size = (n - 4.0,) * 3
+res = tuple(int(round(2.0 * v)) for v in size)
+cap = res[0] * res[1] * res[2]
+p = fluid_amd.default_params(n, n, n, cap)
+p.particle_spawn_cube_resolution[:] = res
+p.particle_spawn_cube_volume = cap
+p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
+p.particle_spawn_cube_size[:] = size
+rank = ranks // 2
+for mode, name in ((0, "list of owned particles"), (1, "every slot            ")):
+    with S.SlabDriver(p, rank, ranks, particle_capacity=cap, pressure_iterations=iters, device=0) as drv:
+        drv.engine.set_option(E.OPT_PARTICLE_SORT, mode)
+        drv.attach_loopback(True, True)
+        drv.run_init()
+        for _ in range(3):
+            drv.run_step()
+        drv.engine.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            drv.run_step()
+        drv.engine.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / 5
+        drv.engine.enable_timing(True)
+        drv.engine.reset_timing()
+        for _ in range(2):
+            drv.run_step()
+        drv.engine.sync()
+        t = drv.engine.section_times()
+        sec = {k: round(v[0] / 2, 3) for k, v in t.items() if v[1] and k[:2] in ("01", "14")}
+        print(f"rank {rank} of {ranks}, full tank {n}^3, {cap} slots, {name}: {ms:8.3f} ms/step   "
+              f"entries {drv.engine.get_stat(E.STAT_PARTICLE_ENTRIES)}   {sec}")

@@ -160,6 +160,23 @@ struct fluid_ctx {
     int wide_lo = 0, wide_hi = 0;
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
     uint32_t leavers_capacity = 0;
+    // the owned list of a slab context (kernels_sampler.h: OwnedList), outside the arena: 2 x 4 B per slot
+    struct Owned {
+        uint32_t* slots[2] = {nullptr, nullptr};  // the list and the buffer the next squeeze writes
+        uint32_t* counters = nullptr;             // device: [0] entries appended, [1] holes made
+        uint32_t n = 0;       // entries, holes included
+        uint32_t holes = 0;
+        bool valid = false;   // the list matches the particle buffer
+        bool failed = false;  // could not be allocated: every slot is looked at, as without it
+        uint64_t squeezes = 0;
+    } own;
+    OwnedList owned_list() const {
+        OwnedList o;
+        o.slots = own.valid ? own.slots[0] : nullptr;
+        o.counters = own.counters;
+        o.capacity = (uint32_t)particle_capacity;
+        return o;
+    }
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
     bool rhs_valid = false;       // b_i matches DIVERGENCES and rho, dx, dt
     bool bg_valid[3] = {false, false, false};  // non-water cells of work[i] hold their constants
@@ -893,6 +910,74 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
 // FLUID_OPT_PARTICLE_SORT: 0 = on for whole-grid contexts with at least 4 M particle slots, 1 = off,
 // 2 = on whatever the size, 3 = on and sorted again before every 01 (tests), 4 = on, sorted once and never
 // again (tests: strays pile up).
+// ---- the owned list of a slab context ---------------------------------------------------------------------
+// FLUID_OPT_PARTICLE_SORT = 1 ("off": plain slot order) switches it off too.
+bool own_wanted(const fluid_ctx* c) {
+    return c->is_slab && !c->own.failed && c->particle_capacity != 0 && c->particle_capacity < 0xFFFFFFFFull &&
+           c->opt[FLUID_OPT_PARTICLE_SORT] != 1;
+}
+void own_release(fluid_ctx* c) {
+    for (auto*& q : c->own.slots)
+        if (q) (void)hipFree(q), q = nullptr;
+    if (c->own.counters) (void)hipFree(c->own.counters), c->own.counters = nullptr;
+    c->own.valid = false;
+}
+// n and holes as the device has them (synchronises the stream)
+int own_read(fluid_ctx* c) {
+    if (!c->own.valid) return FLUID_OK;
+    uint32_t v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(v, c->own.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (v[0] > c->particle_capacity)  // more entries than slots: a slot listed twice, which own_* rules out
+        return c->fail(FLUID_ERR_HIP, "owned list overflow (%u entries, %llu slots)", v[0],
+                       (unsigned long long)c->particle_capacity);
+    c->own.n = v[0];
+    c->own.holes = v[1];
+    return FLUID_OK;
+}
+// after 00_init_particles and uploads: list what the buffer holds
+int own_rebuild(fluid_ctx* c) {
+    c->own.valid = false;
+    if (!own_wanted(c)) return FLUID_OK;
+    if (!c->own.counters) {
+        bool ok = true;
+        for (auto*& q : c->own.slots) ok = ok && hipMalloc(&q, c->particle_capacity * 4) == hipSuccess;
+        ok = ok && hipMalloc(&c->own.counters, 8) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            own_release(c);
+            c->own.failed = true;
+            return FLUID_OK;
+        }
+    }
+    HIP_TRY(c, hipMemsetAsync(c->own.counters, 0, 8, c->stream));
+    c->own.valid = true;  // owned_list() hands out the list from here on
+    hipLaunchKernelGGL(k_owned_build, dim3((unsigned)((c->particle_capacity + 255) / 256)), dim3(256), 0,
+                       c->stream, c->particles(), c->particle_capacity, c->pk.active_w, c->owned_list());
+    HIP_TRY(c, hipGetLastError());
+    return own_read(c);
+}
+// squeeze the holes out when they are a quarter of the list, or when `incoming` more entries would not fit
+int own_squeeze_if_needed(fluid_ctx* c, uint32_t incoming) {
+    auto& o = c->own;
+    if (!o.valid || o.holes == 0) return FLUID_OK;
+    const bool tight = (uint64_t)o.n + incoming > c->particle_capacity;
+    const bool always = c->opt[FLUID_OPT_PARTICLE_SORT] == 3;  // test mode
+    if (!tight && !always && (o.holes < 65536u || o.holes < o.n / 4u)) return FLUID_OK;
+    const uint32_t n = o.n;
+    HIP_TRY(c, hipMemsetAsync(o.counters, 0, 8, c->stream));
+    std::swap(o.slots[0], o.slots[1]);
+    hipLaunchKernelGGL(k_owned_compact, dim3((n + 255) / 256), dim3(256), 0, c->stream, o.slots[1], n,
+                       c->owned_list());
+    HIP_TRY(c, hipGetLastError());
+    o.squeezes++;
+    return own_read(c);
+}
+// entries 01, 14 and the search for leavers look at: the list's, or every slot
+static inline uint64_t particle_entries(const fluid_ctx* c) {
+    return c->own.valid ? c->own.n : c->particle_capacity;
+}
+
 bool psort_wanted(const fluid_ctx* c) {
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
     if (c->is_slab || c->ps.failed || c->particle_capacity == 0 || c->particle_capacity >= (1ull << 32) ||
@@ -1110,6 +1195,10 @@ int run_section_impl(fluid_ctx* c, int section) {
             psort_reset(c);  // slot order, in the arena's buffer
             hipLaunchKernelGGL(k00_init_particles, dim3(pblocks), dim3(256), 0, c->stream,
                                c->particles(), c->particle_capacity, pk, g, c->is_slab ? 1 : 0);
+            if (c->is_slab) {
+                const int rc_own = own_rebuild(c);
+                if (rc_own) return rc_own;
+            }
             break;
         case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES: {
             const int rc = fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
@@ -1137,11 +1226,12 @@ int run_section_impl(fluid_ctx* c, int section) {
                     rc = psort_count(c, dens, c->pbricks(), bk);
                     if (rc) return rc;
                 } else {
-                    const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
-                    const unsigned blocks =
-                        (unsigned)((c->particle_capacity + per_block - 1) / per_block);
-                    hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
-                                       c->particles(), c->particle_capacity, dens, g, pk, c->pbricks(), bk);
+                    const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD, n = particle_entries(c);
+                    const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+                    if (blocks)
+                        hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                                           c->particles(), n, dens, g, pk, c->pbricks(), bk,
+                                           c->owned_list().slots);
                 }
             }
             c->dens_zero = false;
@@ -1160,11 +1250,12 @@ int run_section_impl(fluid_ctx* c, int section) {
                 rc = psort_count(c, dens, nullptr, bk);
                 if (rc) return rc;
             } else {
-                const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD;
-                const unsigned blocks = (unsigned)((c->particle_capacity + per_block - 1) / per_block);
-                hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
-                                   c->particles(), c->particle_capacity, dens, g, pk,
-                                   (uint8_t*)nullptr, bk);
+                const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD, n = particle_entries(c);
+                const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+                if (blocks)
+                    hipLaunchKernelGGL(k01_update_densities, dim3(blocks), dim3(K01_THREADS), 0, c->stream,
+                                       c->particles(), n, dens, g, pk, (uint8_t*)nullptr, bk,
+                                       c->owned_list().slots);
             }
             c->dens_zero = false;
             break;
@@ -1370,8 +1461,10 @@ int run_section_impl(fluid_ctx* c, int section) {
                 hipLaunchKernelGGL(k14_binned, dim3(blocks), dim3(256), 0, c->stream, V1, c->particles(),
                                    c->ps.bin_start, c->ps.bk, g, pk, c->flags(), parts);
             } else {
-                hipLaunchKernelGGL(k14_particles, dim3(pblocks), dim3(256), 0, c->stream, V1,
-                                   c->particles(), c->particle_capacity, g, pk, c->flags());
+                const uint64_t n = particle_entries(c);
+                if (n)
+                    hipLaunchKernelGGL(k14_particles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                                       V1, c->particles(), n, g, pk, c->flags(), c->owned_list().slots);
             }
             break;
         default:
@@ -1640,6 +1733,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->wide) (void)hipFree(c->wide);
     psort_release(c);
+    own_release(c);
     if (c->blur_tmp) (void)hipFree(c->blur_tmp);
     if (c->mc_tables) (void)hipFree(c->mc_tables);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
@@ -1773,6 +1867,8 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
             const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
             hipLaunchKernelGGL(k_particles_filter, dim3(blocks), dim3(256), 0, c->stream,
                                c->particles(), c->particle_capacity, c->g);
+            const int rc_own = own_rebuild(c);
+            if (rc_own) return rc_own;
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -2606,6 +2702,12 @@ int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
         case FLUID_STAT_PARTICLE_BINNED:
             *value = c->ps.binned ? 1 : 0;
             return FLUID_OK;
+        case FLUID_STAT_PARTICLE_ENTRIES:
+            *value = particle_entries(c);
+            return FLUID_OK;
+        case FLUID_STAT_OWNED_SQUEEZES:
+            *value = c->own.squeezes;
+            return FLUID_OK;
         case FLUID_STAT_PARTICLE_STRAYS: {
             uint32_t v[2] = {0, 0};
             if (c->ps.binned && c->ps.stray_count) {
@@ -2773,12 +2875,20 @@ int fluid_particles_collect(fluid_ctx* c, int reset_lists, uint32_t counts[2], u
     counts[0] = counts[1] = 0;
     *left_behind = 0;
     if (!c->is_slab || c->particle_capacity == 0) return FLUID_OK;
-    if (reset_lists) HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));
-    const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
-    hipLaunchKernelGGL(k_particles_collect_leavers, dim3(blocks), dim3(256), 0, c->stream,
-                       c->particles(), c->particle_capacity, c->g, c->migrate_lists());
-    HIP_TRY(c, hipGetLastError());
-    return read_migrate_counts(c, counts, left_behind);
+    if (reset_lists) {
+        HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));
+        const int rc_own = own_squeeze_if_needed(c, 0);  // once per step: the holes of the steps before
+        if (rc_own) return rc_own;
+    }
+    const uint64_t n = particle_entries(c);
+    if (n) {
+        hipLaunchKernelGGL(k_particles_collect_leavers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           c->stream, c->particles(), n, c->g, c->migrate_lists(), c->owned_list());
+        HIP_TRY(c, hipGetLastError());
+    }
+    int rc = read_migrate_counts(c, counts, left_behind);
+    if (rc == FLUID_OK) rc = own_read(c);
+    return rc;
 }
 
 int fluid_particles_adopt_received(fluid_ctx* c, uint32_t from_below, uint32_t from_above,
@@ -2790,17 +2900,22 @@ int fluid_particles_adopt_received(fluid_ctx* c, uint32_t from_below, uint32_t f
                        from_above, c->leavers_capacity);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));  // the send lists have been sent
+    {   // room for what may be adopted (a slot is listed at most once, so without holes it always fits)
+        const int rc_own = own_squeeze_if_needed(c, from_below + from_above);
+        if (rc_own) return rc_own;
+    }
     const uint32_t n[2] = {from_below, from_above};
     for (int src = 0; src < 2; src++) {
         if (n[src] == 0) continue;
         // from below: travelling up (dir 1); from above: travelling down (dir 0)
         hipLaunchKernelGGL(k_particles_adopt, dim3((n[src] + 255) / 256), dim3(256), 0, c->stream,
                            c->particles(), c->particle_capacity, c->g, c->leavers(2 + src), n[src],
-                           src == 0 ? 1 : 0, c->migrate_lists());
+                           src == 0 ? 1 : 0, c->migrate_lists(), c->owned_list(), c->pk.active_w);
         HIP_TRY(c, hipGetLastError());
     }
     uint32_t over = 0;
     int rc = read_migrate_counts(c, forwarded, &over);
+    if (rc == FLUID_OK) rc = own_read(c);
     if (rc) return rc;
     if (over)  // cannot happen while every rank's lists have the same capacity (forwarded <= received)
         return c->fail(FLUID_ERR_OUT_OF_MEMORY, "%u forwarded particles did not fit the send lists", over);

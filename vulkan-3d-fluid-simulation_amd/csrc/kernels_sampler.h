@@ -466,11 +466,19 @@ __global__ void k_max_abs_vz(const float4* __restrict__ v1, int64_t cells, uint3
 }
 
 // 14_particles/particles.comp:45-51
+// owned (Z-slab contexts, optional): the slots of the particles this slab holds, `capacity` entries of which
+// some are OWNED_HOLE (see "the owned list" below); without it every slot of the buffer is looked at
+constexpr uint32_t OWNED_HOLE = 0xFFFFFFFFu;
 __global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict__ particles,
                               uint64_t capacity, GridK g, ParamsK p,
-                              uint32_t* __restrict__ violation) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                              uint32_t* __restrict__ violation, const uint32_t* __restrict__ owned) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
+    if (owned) {
+        const uint32_t slot = owned[i];
+        if (slot == OWNED_HOLE) return;
+        i = slot;
+    }
     float4 q = particles[i];
     if (q.w == p.active_w) {  // :48
         const Axes axes = make_axes(g);
@@ -524,31 +532,90 @@ __device__ __forceinline__ bool migrate_append(const MigrateLists& m, int dir, f
     m.send[dir][slot] = l;
     return true;
 }
-// list the particles this slab holds but does not own and bury their slots; a particle that finds its
-// list full stays where it is (the host runs another round)
-__global__ void k_particles_collect_leavers(float4* __restrict__ particles, uint64_t capacity,
-                                            GridK g, MigrateLists m) {
+// The owned list (Z-slab contexts): 01, 14 and the search for leavers would otherwise read every slot of a
+// buffer sized for the particles of ALL slabs, on every rank, every step.  The list holds the slots of the
+// active particles this slab owns; a particle that leaves turns its entry into OWNED_HOLE, one that is adopted
+// is appended, and the host squeezes the holes out when they pile up (engine.hip: own_*).  The order of the
+// entries means nothing: 01's counts are integer atomics and 14 treats every particle on its own.
+struct OwnedList {
+    uint32_t* slots;    // entries
+    uint32_t* counters; // [0] entries appended so far, [1] holes made so far
+    uint32_t capacity;  // entries the list can hold
+};
+// append the slots of the lanes that want to, one atomic per wavefront, the lanes' entries in lane order
+__device__ __forceinline__ void owned_append(const OwnedList& o, bool want, uint32_t slot) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u), leader = __builtin_ctzll(m);
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(o.counters, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want) {
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (pos < o.capacity) o.slots[pos] = slot;  // counters[0] > capacity tells the host (never: see own_*)
+    }
+}
+// after 00 and after uploads: list the active particles the buffer holds (the others' slots are tombstones)
+__global__ void k_owned_build(const float4* __restrict__ particles, uint64_t capacity, float active_w,
+                              OwnedList o) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = i < capacity && particles[i < capacity ? i : 0].w == active_w;
+    owned_append(o, want, (uint32_t)i);
+}
+// squeeze the holes out: src (n entries) -> o
+__global__ void k_owned_compact(const uint32_t* __restrict__ src, uint32_t n, OwnedList o) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = i < n ? src[i] : OWNED_HOLE;
+    owned_append(o, slot != OWNED_HOLE, slot);
+}
+
+// list the particles this slab holds but does not own and bury their slots; a particle that finds its
+// list full stays where it is (the host runs another round).  With an owned list: `capacity` of its entries
+// are looked at instead of every slot.
+__global__ void k_particles_collect_leavers(float4* __restrict__ particles, uint64_t capacity,
+                                            GridK g, MigrateLists m, OwnedList o) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
+    const uint64_t entry = i;
+    if (o.slots) {
+        const uint32_t slot = o.slots[entry];
+        if (slot == OWNED_HOLE) return;
+        i = slot;
+    }
     const float4 q = particles[i];
     if (is_tombstone(q)) return;
     const int pl = particle_owner_plane(q.z, g.Dg) - g.z0;
     if ((unsigned)pl < (unsigned)g.Dl) return;
-    if (migrate_append(m, pl < 0 ? 0 : 1, q, (uint32_t)i)) particles[i] = tombstone();
+    if (migrate_append(m, pl < 0 ? 0 : 1, q, (uint32_t)i)) {
+        particles[i] = tombstone();
+        if (o.slots) {
+            o.slots[entry] = OWNED_HOLE;
+            atomicAdd(o.counters + 1, 1u);
+        }
+    }
 }
 // entries received from the neighbour below travel up (dir 1), those from above travel down (dir 0):
 // adopt what this slab owns, pass the rest on
 __global__ void k_particles_adopt(float4* __restrict__ particles, uint64_t capacity, GridK g,
                                   const Leaver* __restrict__ list, uint32_t count, int dir,
-                                  MigrateLists m) {
+                                  MigrateLists m, OwnedList o, float active_w) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const Leaver l = list[i];
-    if (l.index >= capacity) return;
-    if (slab_owns(g, l.data.z))
-        particles[l.index] = l.data;
-    else
-        migrate_append(m, dir, l.data, l.index);
+    bool adopted = false;
+    Leaver l;
+    l.index = 0u;
+    l.data = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < count) {
+        l = list[i];
+        if (l.index < capacity) {
+            if (slab_owns(g, l.data.z)) {
+                particles[l.index] = l.data;
+                adopted = l.data.w == active_w;
+            } else {
+                migrate_append(m, dir, l.data, l.index);
+            }
+        }
+    }
+    if (o.slots) owned_append(o, adopted, l.index);
 }
 
 // 00_init_particles/init_particles.comp:27-50
@@ -596,7 +663,8 @@ constexpr uint32_t K01_EMPTY = 0xFFFFFFFFu;
 __global__ void __launch_bounds__(K01_THREADS)
 k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
                      uint32_t* __restrict__ dens, GridK g, ParamsK p,
-                     uint8_t* __restrict__ particle_bricks, BrickK bk) {
+                     uint8_t* __restrict__ particle_bricks, BrickK bk, const uint32_t* __restrict__ owned) {
+    // owned (Z-slab contexts, optional): `capacity` entries of the owned list instead of every slot
     // particle_bricks (optional): one byte per activity brick, set where a particle is counted
     // (quiet_bricks.h: the sections before 06 skip bricks far from old and new water)
     auto mark = [&](uint32_t key) {
@@ -617,11 +685,19 @@ k01_update_densities(const float4* __restrict__ particles, uint64_t capacity,
     for (int k = 0; k < K01_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * K01_THREADS + threadIdx.x;  // coalesced 16-B loads
         if (i >= capacity) break;
-        const float4 q = particles[i];
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool there = true;
+        if (owned) {
+            const uint32_t slot = owned[i];
+            there = slot != OWNED_HOLE;
+            if (there) q = particles[slot];
+        } else {
+            q = particles[i];
+        }
         // cell this particle counts towards, or K01_EMPTY (inactive, outside the grid, another slab's)
         uint32_t key = K01_EMPTY;
         int cx, cy, cz;
-        if (q.w == p.active_w &&  // :33
+        if (there && q.w == p.active_w &&  // :33
             trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) && trunc_index(q.z, g.Dg, cz)) {
             cz -= g.z0;  // slab contexts count only their own planes
             if ((unsigned)cz < (unsigned)g.Dl) key = (uint32_t)cidx(g, cx, cy, cz);

@@ -64,6 +64,7 @@ OPT_LAUNCH_BOX = 6
 OPT_EDGE_STREAM = 7
 OPT_PARTICLE_SORT = 8
 STAT_BRICKS, STAT_QUIET_BRICKS, STAT_PARTICLE_SORTS, STAT_PARTICLE_STRAYS, STAT_PARTICLE_BINNED = 0, 1, 2, 3, 4
+STAT_PARTICLE_ENTRIES, STAT_OWNED_SQUEEZES = 5, 6
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_OOM = (
     0, -1, -2, -3, -4, -5, -6)
