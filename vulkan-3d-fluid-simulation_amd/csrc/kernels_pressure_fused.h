@@ -173,7 +173,7 @@ constexpr int FUSED_PAD = 4;  // floats of padding on each side of an LDS row (k
 // (addresses, waits, the barrier) is paid once per RG rows, and RG independent rows interleave in the
 // one instruction stream — the SIMDs execute their wavefronts one after the other (oldest first) between
 // two barriers, so work per wavefront, not wavefronts per SIMD, is what fills the VALU.
-constexpr int fused_waves(int rg) { return rg == 1 ? 16 : 8; }
+constexpr int fused_waves(int rg) { return rg == 1 ? 16 : rg == 2 ? 12 : 8; }
 template <int NT, int RG>
 struct FusedGeom {
     static constexpr int WAVES = fused_waves(RG);

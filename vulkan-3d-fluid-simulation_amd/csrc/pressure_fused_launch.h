@@ -139,13 +139,17 @@ static inline int cu_count() {
     return n;
 }
 
-// rows per wavefront (FusedGeom) by x tiles per row, measured on MI355X (Jacobi iterations/s, RG = 1 / 2 / 3):
-//   NT = 1 (256^3)          27.3 k / 24.6 k / 43.7 k    R = 16 / 16 / 24 rows per workgroup
-//   NT = 2 (512^3)          5.09 k / 5.58 k / 5.76 k    R =  8 /  8 / 12 (225 VGPRs, no spill since the plane
-//                                                       step was reordered; before that: 5.60 / 5.61 / 5.22)
-//   NT = 4 (1024 x 1024 x 64)  9.3 k / 8.7 k / 11.9 k   R =  4 /  4 /  6: the halo rows are half / a third
-// Three rows everywhere, then: also the 512 x 512 x 64 slab of an 8-way run (+ 10 %) and the loop inside a
-// full-tank step (37.0 -> 35.4 ms).  FLUID_FUSED_RG = 1, 2 or 3 overrides it.
+// rows per wavefront (FusedGeom) by x tiles per row, measured on MI355X (Jacobi iterations/s):
+//                              RG = 1, 16 waves / RG = 2, 8 waves / RG = 3, 8 waves / RG = 2, 12 waves
+//   NT = 1 (256^3)             27.3 k / 24.6 k / 43.7 k (47.1 k with the XCD ranges) / 46.7 k
+//   NT = 2 (512^3)             5.09 k / 5.58 k / 5.76 k / 5.73 k     (RG 3: 225 VGPRs, no spill since the
+//                                                       plane step was reordered; before that 5.22 k)
+//   NT = 4 (1024 x 1024 x 64)  9.3 k / 8.7 k / 11.8 k / 12.6 k
+// Rows per workgroup: 16 / NT with one or two rows per wavefront on 16 or 8 wavefronts, 24 / NT with three rows
+// on 8 wavefronts or two rows on 12 (160 VGPRs: three wavefronts per SIMD instead of two) — at NT = 4 a third
+// instead of half of the rows are halo.  Three rows on 8 wavefronts, then, and two on 12 for the widest grids;
+// also measured with three: the 512 x 512 x 64 slab of an 8-way run (+ 10 % over two on 8) and the loop inside
+// a full-tank step (37.0 -> 35.4 ms).  FLUID_FUSED_RG = 1, 2 or 3 overrides it.
 static inline int fused_rows_per_wave(int nt) {
     static const int forced = [] {
         const char* e = getenv("FLUID_FUSED_RG");
@@ -153,8 +157,7 @@ static inline int fused_rows_per_wave(int nt) {
         return (v >= 1 && v <= 3) ? v : 0;
     }();
     if (forced) return forced;
-    (void)nt;
-    return 3;
+    return nt >= 3 ? 2 : 3;
 }
 
 template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false>
@@ -281,7 +284,7 @@ static hipError_t launch_rg(hipStream_t s, const uint8_t* mask, const float* rhs
         const int rows = std::max(0, std::min(box.y_hi, g.H) - box.y_lo);
         const int planes = (rg.zout_lo == 0 && rg.zout_hi == g.Dl) ? std::max(0, box.z_hi - box.z_lo)
                                                                    : rg.zout_hi - rg.zout_lo;
-        const int ty = (8 / NT) * rows_per_wave - 2;
+        const int ty = (fused_waves(rows_per_wave) / NT) * rows_per_wave - 2;
         const int tiles = (rows + ty - 1) / std::max(ty, 1), chunks = (planes + 15) / 16;
         if (tiles * chunks < 2 * cu_count()) rows_per_wave = 1;
     }
