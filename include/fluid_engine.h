@@ -593,8 +593,9 @@ typedef enum fluid_stat {
     FLUID_STAT_PARTICLE_STRAYS = 3,  /* particles the last 01 found outside the bin they are stored in     */
     FLUID_STAT_PARTICLE_BINNED = 4,  /* 1 while 01 and 14 run on bins; 0 in slot order or while the flow    */
                                      /* moves the particles faster than sorting pays (tried again later)    */
-    FLUID_STAT_PARTICLE_ENTRIES = 5, /* entries 01, 14 and the search for leavers look at: every slot, or — */
-                                     /* Z-slab contexts — the entries of the list of particles the slab owns */
+    FLUID_STAT_PARTICLE_ENTRIES = 5, /* Z-slab contexts: entries (holes included) of the list of particles the */
+                                     /* slab owns, which the search for leavers walks, and 01 and 14 too unless */
+                                     /* it names more than 4/5 of the slots; otherwise the number of slots      */
     FLUID_STAT_OWNED_SQUEEZES = 6    /* times that list had its holes squeezed out                          */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);

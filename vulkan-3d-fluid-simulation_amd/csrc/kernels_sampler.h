@@ -555,18 +555,65 @@ __device__ __forceinline__ void owned_append(const OwnedList& o, bool want, uint
         if (pos < o.capacity) o.slots[pos] = slot;  // counters[0] > capacity tells the host (never: see own_*)
     }
 }
+// Building and squeezing keep slot order inside a block's 4096 candidates (one atomic per block; the blocks'
+// runs land in any order): 01 folds the particles of 4096 consecutive entries in an LDS table before it
+// touches the image, which pays when they share cells — particles of neighbouring slots do (they were spawned
+// side by side), particles of 64 unrelated wavefront-sized runs do not (01 of a dam break, all of it in one
+// slab: 0.39 ms over every slot, 0.63 ms over a list appended wavefront by wavefront).
+constexpr int OWNED_BLOCK = 256, OWNED_PER_THREAD = 16;
+template <typename Candidate>
+__device__ __forceinline__ void owned_append_block(const OwnedList& o, uint64_t n, Candidate candidate) {
+    // candidate(i, slot) -> does entry i of the block's range go into the list, and with which slot
+    __shared__ uint32_t part[OWNED_PER_THREAD][OWNED_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const uint64_t base = (uint64_t)blockIdx.x * (OWNED_BLOCK * OWNED_PER_THREAD);
+    uint32_t slot[OWNED_PER_THREAD];
+    unsigned long long mask[OWNED_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < OWNED_PER_THREAD; k++) {
+        const uint64_t i = base + (uint64_t)k * OWNED_BLOCK + threadIdx.x;
+        slot[k] = OWNED_HOLE;
+        const bool want = i < n && candidate(i, slot[k]);
+        mask[k] = __builtin_amdgcn_ballot_w64(want);
+        if (lane == 0) part[k][wave] = (uint32_t)__builtin_popcountll(mask[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0u;
+        for (int k = 0; k < OWNED_PER_THREAD; k++)
+            for (int w = 0; w < OWNED_BLOCK / 64; w++) {
+                const uint32_t c = part[k][w];
+                part[k][w] = total;
+                total += c;
+            }
+        block_base = total ? atomicAdd(o.counters, total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OWNED_PER_THREAD; k++) {
+        if ((mask[k] >> lane) & 1ull) {
+            const uint32_t pos = block_base + part[k][wave] +
+                                 (uint32_t)__builtin_popcountll(mask[k] & ((1ull << lane) - 1ull));
+            if (pos < o.capacity) o.slots[pos] = slot[k];
+        }
+    }
+}
 // after 00 and after uploads: list the active particles the buffer holds (the others' slots are tombstones)
-__global__ void k_owned_build(const float4* __restrict__ particles, uint64_t capacity, float active_w,
-                              OwnedList o) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool want = i < capacity && particles[i < capacity ? i : 0].w == active_w;
-    owned_append(o, want, (uint32_t)i);
+__global__ void __launch_bounds__(OWNED_BLOCK)
+k_owned_build(const float4* __restrict__ particles, uint64_t capacity, float active_w, OwnedList o) {
+    owned_append_block(o, capacity, [&](uint64_t i, uint32_t& slot) {
+        slot = (uint32_t)i;
+        return particles[i].w == active_w;
+    });
 }
 // squeeze the holes out: src (n entries) -> o
-__global__ void k_owned_compact(const uint32_t* __restrict__ src, uint32_t n, OwnedList o) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t slot = i < n ? src[i] : OWNED_HOLE;
-    owned_append(o, slot != OWNED_HOLE, slot);
+__global__ void __launch_bounds__(OWNED_BLOCK)
+k_owned_compact(const uint32_t* __restrict__ src, uint32_t n, OwnedList o) {
+    owned_append_block(o, n, [&](uint64_t i, uint32_t& slot) {
+        slot = src[i];
+        return slot != OWNED_HOLE;
+    });
 }
 
 // list the particles this slab holds but does not own and bury their slots; a particle that finds its
