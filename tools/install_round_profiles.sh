@@ -13,6 +13,7 @@ cp $R/dense_stats/dense_kernel_stats.csv $P/full_step_dense_512_kernel_stats.csv
 cp $R/sparse_stats/sparse_kernel_stats.csv $P/full_step_512_kernel_stats.csv
 cp $R/slab_rank_rehearsal.txt $R/slab_one_rank_step.txt $R/sor_time.txt $R/particle_sort_ab.txt \
    $R/particle_sort_longrun.txt $R/surface_time.txt $P/
+[ -f $R/slab_dense_rank_step.txt ] && cp $R/slab_dense_rank_step.txt $P/
 grep -v "^[WE]2026" $R/dense_stats.log > $P/full_step_dense_512_sections.txt
 grep -v "^[WE]2026" $R/sparse_stats.log > $P/full_step_512_sections.txt
 python3 tools/kernel_resources.py > $P/kernel_resources.txt 2>/dev/null

@@ -18,6 +18,7 @@ python3 bench.py --grid 1024 1024 512 --iters 400 --steps 3 --warmup 1 --no-cpu-
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/sparse_stats -o sparse -- python3 $ROOT/tools/full_step_run.py 512 10 > $ROOT/$OUT/sparse_stats.log 2>&1)
 python3 tools/slab_rank_sim.py --ranks 2 4 8 --halo 8 > $OUT/slab_rank_rehearsal.txt 2>&1
 python3 tools/slab_one_rank_step.py > $OUT/slab_one_rank_step.txt 2>&1
+python3 tools/slab_dense_rank_step.py 512 8 > $OUT/slab_dense_rank_step.txt 2>&1
 python3 tools/sor_time.py > $OUT/sor_time.txt 2>&1
 python3 tools/particle_sort_ab.py 512 20 > $OUT/particle_sort_ab.txt 2>&1
 python3 tools/particle_sort_longrun.py 512 400 50 > $OUT/particle_sort_longrun.txt 2>&1
