@@ -56,7 +56,7 @@ def parse_args():
 
 
 FUSED_KERNEL_SOURCES = ["kernels_pressure_fused.h", "pressure_fused_launch.h", "pressure_fused.hip",
-                        "pressure_common.h"]
+                        "pressure_fused_stream.hip", "pressure_common.h"]
 
 
 def kernel_sources_sha16():

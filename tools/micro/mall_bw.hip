@@ -21,6 +21,17 @@ __global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ a, floa
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) b[i] = a[i];
 }
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_nt(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) __builtin_nontemporal_store(((const f4*)a)[i], &((f4*)b)[i]);
+}
+__global__ void __launch_bounds__(256) k_copy_nt2(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&((const f4*)a)[i]), &((f4*)b)[i]);
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main() {
     const size_t max_bytes = (size_t)2 << 30;
@@ -41,8 +52,18 @@ int main() {
             for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, 0, a, b, n / 2);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_c, e0, e1));
         }
-        printf("%6zu MB   | %8.0f  | %8.0f\n", mb, (double)bytes * reps / (ms_r * 1e-3) / 1e9,
-               (double)bytes * reps / (ms_c * 1e-3) / 1e9);
+        float ms_n = 0.f, ms_n2 = 0.f;
+        for (int w = 0; w < 2; w++) {
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy_nt, dim3(256 * 16), dim3(256), 0, 0, a, b, n / 2);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_n, e0, e1));
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy_nt2, dim3(256 * 16), dim3(256), 0, 0, a, b, n / 2);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_n2, e0, e1));
+        }
+        printf("%6zu MB   | %8.0f  | %8.0f | nt store %8.0f | nt load + store %8.0f\n", mb,
+               (double)bytes * reps / (ms_r * 1e-3) / 1e9, (double)bytes * reps / (ms_c * 1e-3) / 1e9,
+               (double)bytes * reps / (ms_n * 1e-3) / 1e9, (double)bytes * reps / (ms_n2 * 1e-3) / 1e9);
     }
     return 0;
 }

@@ -42,8 +42,21 @@ __device__ __forceinline__ void lds_st4(FLUID_LDS float* p, float4 v) {
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* base, unsigned byte_off) {
     return *reinterpret_cast<const uint32_t*>(base + byte_off);
 }
+// NTS: a streaming store.  The next launch reads these bytes again, so they should stay cached when a
+// launch's working set fits the 256 MB memory-side cache (256^3: 48.6 k iterations/s, 37.0 k with streaming
+// stores) and should not take cache space when it does not (512^3: 5 690 -> 5 920; a copy kernel over 1 GB:
+// 4.9 -> 5.2 TB/s, tools/micro/mall_bw.hip).  A template parameter, chosen by the launch code: a wave-uniform
+// branch around the two kinds of store cost the kernel 6 % (hipcc's waits for the loads then include them).
+// The streaming kernels are instantiated in a translation unit of their own (pressure_fused_stream.hip):
+// beside the others they moved the schedule of the one-tile kernel (256^3: - 6 %).
+template <bool NTS>
 __device__ __forceinline__ void st_f4(float* base, unsigned byte_off, float4 v) {
-    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    if constexpr (NTS) {
+        const f32x4 r = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off));
+    } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    }
 }
 
 // ---- the division of pressure.comp:62 without the IEEE division sequence -----------------------------
@@ -329,7 +342,7 @@ __device__ __forceinline__ float4 canon_lane(float4 b, uint32_t m, float4 c, flo
 // Vector-memory operations retire in issue order and the compiler's s_waitcnt counts only what is issued
 // on every path, so the stores carry all their conditions in the EXEC mask (no branch around them): the
 // wait for a step's loads then never includes the stores issued after them.
-template <int NT, int RG, int I, bool WIN, bool KEEP, bool SOR>
+template <int NT, int RG, int I, bool WIN, bool KEEP, bool SOR, bool NTS>
 __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (&row)[RG], float4 (&h)[2],
                                            int zc FLUID_TRACE_ARG) {
     constexpr int buf = I & 1;
@@ -453,9 +466,9 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
         const int64_t oo = (int64_t)(zo_in ? zo : c.zb) * c.plane;
 #pragma unroll
         for (int i = 0; i < RG; i++) {
-            if (wet[i]) st_f4(c.pout + oo, row[i].boff, o[i]);
+            if (wet[i]) st_f4<NTS>(c.pout + oo, row[i].boff, o[i]);
             if (KEEP) {  // the odd iterate, kept only by the last pair of a loop
-                if (wet[i]) st_f4(c.pmid + oo, row[i].boff, row[i].s[SM]);
+                if (wet[i]) st_f4<NTS>(c.pmid + oo, row[i].boff, row[i].s[SM]);
             }
         }
     }
@@ -485,7 +498,7 @@ __device__ __forceinline__ void fused_step(const FusedCtx<NT, RG>& c, FusedRow (
     FT(4);  // barrier
 }
 
-template <int NT, bool WIN, int RG, bool KEEP, bool SOR>
+template <int NT, bool WIN, int RG, bool KEEP, bool SOR, bool NTS = false>
 __global__ void __launch_bounds__(fused_waves(RG) * 64)
 k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
            const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ pmid,
@@ -651,13 +664,13 @@ k12_canon2(const uint8_t* __restrict__ mask, const float* __restrict__ rhs,
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step<NT, RG, 0, WIN, KEEP, SOR>(c, row, h, zc FLUID_TRACE_PASS);
+        fused_step<NT, RG, 0, WIN, KEEP, SOR, NTS>(c, row, h, zc FLUID_TRACE_PASS);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step<NT, RG, 1, WIN, KEEP, SOR>(c, row, h, zc + 1 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 1, WIN, KEEP, SOR, NTS>(c, row, h, zc + 1 FLUID_TRACE_PASS);
         if (k + 2 >= steps) break;
-        fused_step<NT, RG, 2, WIN, KEEP, SOR>(c, row, h, zc + 2 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 2, WIN, KEEP, SOR, NTS>(c, row, h, zc + 2 FLUID_TRACE_PASS);
         if (k + 3 >= steps) break;
-        fused_step<NT, RG, 3, WIN, KEEP, SOR>(c, row, h, zc + 3 FLUID_TRACE_PASS);
+        fused_step<NT, RG, 3, WIN, KEEP, SOR, NTS>(c, row, h, zc + 3 FLUID_TRACE_PASS);
     }
 #ifdef FLUID_FUSED_TRACE
     {

@@ -160,6 +160,28 @@ static inline int fused_rows_per_wave(int nt) {
     return nt >= 3 ? 2 : 3;
 }
 
+// The launch of the kernel with streaming stores (k12_canon2<NT, false, RG, KEEP, false, true>), defined and
+// instantiated in pressure_fused_stream.hip for NT = 2, 4 and RG = 2, 3.
+struct FusedLaunchArgs {
+    dim3 grid;
+    size_t lds;
+    hipStream_t stream;
+    const uint8_t* mask;
+    const float* rhs;
+    const float* pin;
+    float* pout;
+    float* pmid;
+    const uint8_t* bricks;
+    BrickK bk;
+    GridK g;
+    float p_oob;
+    int zchunk;
+    FusedRange r;
+    float omega;
+};
+template <int NT, int RG, bool KEEP>
+hipError_t k12_launch_streaming(const FusedLaunchArgs& a);
+
 template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false>
 static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
@@ -168,6 +190,8 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     // the dynamic-LDS limit is an attribute of the function on a device: once per instantiation and
     // device (a process may hold contexts on several)
     using G = FusedGeom<NT, RG>;
+    // the kernel with streaming stores exists for the full-row Jacobi launches of grids 512 cells wide or wider
+    constexpr bool STREAMING_VARIANT = !WIN && !SOR && NT >= 2 && RG >= 2;
     static bool attr_set[64] = {};
     const size_t lds = G::lds_bytes;
     int dev = 0;
@@ -234,6 +258,16 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     // the halo rows they both read.  Fabric reads of a 512^3 launch: 1.91 -> 1.35 GB (TCC_EA0_RDREQ x 128 B,
     // profiles/round02).  The placement is an observed property of the dispatcher, used for speed only;
     // FLUID_FUSED_XCD=0 turns it off, 2 uses the ranges whatever the model says of them.
+    // streaming stores when the launch's working set (13 B per cell of the planes it covers) is several times the
+    // 256 MB memory-side cache: the next launch then finds none of these bytes cached either way, and they
+    // take no room from the rows the launch itself reads twice (st_f4).  FLUID_FUSED_NT = 0 / 1 overrides it.
+    static const int nt_forced = [] {
+        const char* e = getenv("FLUID_FUSED_NT");
+        return e == nullptr ? -1 : atoi(e);
+    }();
+    const bool streaming =
+        STREAMING_VARIANT && (nt_forced >= 0 ? nt_forced != 0
+                                             : (int64_t)g.W * g.H * (r.zout_hi - r.zout_lo) * 13 >= (int64_t)3 << 29);
     r.xcd_rows = 0;
     for (int& v : r.xcd_start) v = 0;
     static const int xcd_ranges = [] {
@@ -254,6 +288,13 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     bk.nbx = (g.W + BRICK_X - 1) / BRICK_X;
     bk.nby = (g.H + BRICK_Y - 1) / BRICK_Y;
     bk.nbz = (g.Dl + BRICK_Z - 1) / BRICK_Z;
+    if constexpr (STREAMING_VARIANT) {
+        if (streaming) {
+            FusedLaunchArgs a{grid, lds, s, mask, rhs, pin, pout, pmid, bricks, bk, g, p_oob, zchunk, r, omega};
+            return k12_launch_streaming<NT, RG, KEEP>(a);
+        }
+    }
+    (void)streaming;
     hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP, SOR>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout,
                        pmid, bricks, bk, g, p_oob, zchunk, r, omega);
     return hipSuccess;
