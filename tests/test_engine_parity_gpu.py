@@ -5,6 +5,7 @@ arithmetic in fp32 with one rounding per operation in source order (-ffp-contrac
 division), so the stated north-star tolerance ("a stated float tolerance per field") is 0 ulp here;
 any mismatch is a bug, not noise.
 """
+import os
 import zlib
 
 import numpy as np
@@ -19,6 +20,7 @@ from helpers import (IMAGE_FIELDS, assert_bit_equal, assert_bit_equal_any_nan, a
 from oracle_binding import OracleState
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GRID_SECTIONS = ["02_update_water", "03_update_air", "04_compute_extrapolated_velocities",
                  "05_set_extrapolated_velocities", "06_update_cell_types", "07_advect",
@@ -555,6 +557,25 @@ def test_pressure_fused_pairs_match_oracle(size, iters):
         st.run_section("13_fix_divergence")
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2", "velocities_1"],
                            ctx=f"fused second loop {size}: ")
+
+
+def test_pressure_fused_streaming_store_kernels_match_oracle():
+    """The kernels with streaming stores (pressure_fused_stream.hip), which the launch code picks for working
+    sets of 1.6 GB and more (512^3: covered by the property tests there): forced onto small grids of 2 and 4
+    x-tiles in a child process (FLUID_FUSED_NT is read once per process), same test as above."""
+    import subprocess
+    import sys as _sys
+
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import test_engine_parity_gpu as T\n"
+        "for size in [(512, 19, 35), (768, 7, 6), (1024, 5, 4)]:\n"
+        "    for iters in (2, 5, 8):\n"
+        "        T.test_pressure_fused_pairs_match_oracle(size, iters)\n"
+        "print('streaming ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, FLUID_FUSED_NT="1")
+    out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "streaming ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_pressure_fused_sparse_scene_and_bricks():
