@@ -258,16 +258,18 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     // the halo rows they both read.  Fabric reads of a 512^3 launch: 1.91 -> 1.35 GB (TCC_EA0_RDREQ x 128 B,
     // profiles/round02).  The placement is an observed property of the dispatcher, used for speed only;
     // FLUID_FUSED_XCD=0 turns it off, 2 uses the ranges whatever the model says of them.
-    // streaming stores when the launch's working set (13 B per cell of the planes it covers) is several times the
-    // 256 MB memory-side cache: the next launch then finds none of these bytes cached either way, and they
-    // take no room from the rows the launch itself reads twice (st_f4).  FLUID_FUSED_NT = 0 / 1 overrides it.
+    // streaming stores when the launch's working set (13 B per cell of the planes it covers) is larger than the
+    // 256 MB memory-side cache by a margin: little of what it writes is then still cached when the next launch
+    // reads it, and the stores take no room from the rows the launch itself reads twice (st_f4).  Measured with
+    // the stores forced either way: 0.27 GB (slab of an 8-way 512^3 run) - 2.5 %, 0.44 GB (4-way) + 1.3 %,
+    // 0.87 GB (2-way; 1024 x 1024 x 64) + 2.4 % / + 1.4 %, 1.7 GB (512^3) + 4 %.  FLUID_FUSED_NT = 0 / 1 overrides.
     static const int nt_forced = [] {
         const char* e = getenv("FLUID_FUSED_NT");
         return e == nullptr ? -1 : atoi(e);
     }();
     const bool streaming =
         STREAMING_VARIANT && (nt_forced >= 0 ? nt_forced != 0
-                                             : (int64_t)g.W * g.H * (r.zout_hi - r.zout_lo) * 13 >= (int64_t)3 << 29);
+                                             : (int64_t)g.W * g.H * (r.zout_hi - r.zout_lo) * 13 >= (int64_t)3 << 27);
     r.xcd_rows = 0;
     for (int& v : r.xcd_start) v = 0;
     static const int xcd_ranges = [] {
