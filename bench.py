@@ -13,6 +13,14 @@ With N > 1 the grid is split into Z slabs, one process per GPU, driven by the C+
 (torch.distributed only carries the communicator's unique id and the barriers around the timed
 region); the total grid is fixed (strong scaling).
 
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N
+ranks: the parent never touches the GPU, spawns one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR = 127.0.0.1 / MASTER_PORT set), relays rank 0's JSON line and exits non-zero with a one-line
+reason if a rank fails, the box has fewer GPUs than ranks, or the run exceeds --launch-timeout.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (WORLD_SIZE set) the process
+IS a rank.  The N > 1 line adds n_ranks_rccl (ncclCommCount), exchange_ms_per_sweep, overlap_mode and —
+after the timed region — a checksum of PRESSURES_1 over all ranks against a one-rank run of the same grid.
+
 The same JSON line also carries
   roofline     : the Jacobi kernel's algorithmic bytes (13 B/cell/sweep) / its average launch
                  duration from HIP events on the engine's stream, against 8 TB/s HBM peak;
@@ -37,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 JACOBI_BYTES_PER_CELL = 13.0   # Pin 4 + div 4 + type 1 + Pout 4
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -52,7 +60,13 @@ def parse_args():
     ap.add_argument("--full-step-steps", type=int, default=20)
     ap.add_argument("--no-surface", action="store_true",
                     help="skip the surface-prep figure (128^3 + 640^3 detailed grid, 4.3 GB)")
-    return ap.parse_args()
+    ap.add_argument("--no-checksum", action="store_true",
+                    help="N > 1: skip the cross-rank PRESSURES_1 checksum against a one-rank run")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (the launcher's own test)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="seconds the self-launched ranks get before they are killed")
+    return ap.parse_args(argv)
 
 
 FUSED_KERNEL_SOURCES = ["kernels_pressure_fused.h", "pressure_fused_launch.h", "pressure_fused.hip",
@@ -378,19 +392,288 @@ def slab_full_step_bench(size, iters, steps, dist_ctx, overlap=None):
     return out
 
 
-def main():
-    args = parse_args()
+# ---- self-launch: one child process per GPU ---------------------------------------------------------------
+def visible_gpu_count():
+    """hipGetDeviceCount, asked in a throwaway child process: the launcher itself must never initialise
+    the GPU (its children do, and a process that has may not be replaced or forked from)."""
+    import subprocess
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "for name in ('libamdhip64.so', 'libamdhip64.so.7', '/opt/rocm/lib/libamdhip64.so'):\n"
+            "    try:\n"
+            "        h = ctypes.CDLL(name)\n"
+            "    except OSError:\n"
+            "        continue\n"
+            "    print(n.value if h.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0)\n"
+            "    break\n"
+            "else:\n"
+            "    print(0)\n")
+    try:
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        return int(res.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: spawn the N ranks, relay rank 0's JSON line.
+    Returns the exit code.  No HIP call, no torch import in this process."""
+    import signal
+    import subprocess
+    import threading
+
+    n = args.gpus
+    child = os.environ.get("FLUID_BENCH_CHILD")  # tests: another rank program (tests/bench_child_standin.py)
+    if child is None:
+        have = visible_gpu_count()
+        if have < n:
+            print(f"bench.py --gpus {n}: {have} GPU(s) visible to this process (hipGetDeviceCount); one rank "
+                  f"per GPU needs {n}", file=sys.stderr, flush=True)
+            return 2
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, child or os.path.abspath(__file__)] + list(argv), env=env,
+            stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
+            start_new_session=True))   # a process group of its own: killable without a pattern
+    last_json = [None]
+
+    def relay():
+        for line in procs[0].stdout:
+            if line.startswith("{"):
+                last_json[0] = line.rstrip("\n")
+            else:
+                sys.stderr.write(line)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 10
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                q.wait()
+
+    deadline = time.time() + args.launch_timeout
+    why = None
+    while True:
+        codes = [q.poll() for q in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            # the others are (or will be) stuck in a collective with a rank that is gone
+            grace = time.time() + 15
+            while time.time() < grace and any(q.poll() is None for q in procs):
+                time.sleep(0.2)
+            why = "rank(s) failed: " + ", ".join(f"rank {r} exit code {c}" for r, c in bad)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            why = f"the {n} ranks did not finish within --launch-timeout {args.launch_timeout:.0f} s"
+            break
+        time.sleep(0.2)
+    if why is not None:
+        kill_all()
+        print(f"bench.py --gpus {n}: {why}", file=sys.stderr, flush=True)
+        return 1
+    reader.join(timeout=10)
+    if last_json[0] is None:
+        print(f"bench.py --gpus {n}: the ranks exited cleanly but rank 0 printed no JSON line",
+              file=sys.stderr, flush=True)
+        return 1
+    print(last_json[0], flush=True)
+    return 0
+
+
+# ---- a rank of an N > 1 run -----------------------------------------------------------------------------
+OVERLAP_NAMES = {0: "inline", 1: "split_pass_before_exchange", 2: "split_passes_before_and_after"}
+
+
+def image_checksum(a):
+    """Order-independent exact checksum of an image's bits: (sum of the 32-bit words mod 2^64, their XOR,
+    the number of words).  Slabs add / XOR to the whole grid's."""
+    words = np.ascontiguousarray(a).view(np.uint32).ravel()
+    with np.errstate(over="ignore"):
+        total = int(words.sum(dtype=np.uint64))
+    return total, int(np.bitwise_xor.reduce(words)) if words.size else 0, int(words.size)
+
+
+class EngineRanks:
+    """What a rank computes with: the HIP engine behind the C++ slab driver, RCCL attached (the product).
+    tests/bench_child_standin.py substitutes a host stand-in to run this file's rank code without a GPU."""
+
+    def make_solver(self, size, iters, dist_ctx, args):
+        from fluid_amd import engine as E
+        from fluid_amd import slab as S
+        solver = S.SlabDriver.create_full_fluid(size, iters, dist_ctx)
+        solver.engine.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
+        return solver
+
+    def one_rank_pressures_1(self, size, iters, device, args):
+        """PRESSURES_1 after the same step (12a, 12b, the loop) on the whole grid in one context."""
+        import fluid_amd
+        from fluid_amd import engine as E
+        from fluid_amd import scenes
+        w, h, d = size
+        with fluid_amd.FluidEngine(fluid_amd.default_params(w, h, d, 0), particle_capacity=0,
+                                   pressure_iterations=iters, device=device) as eng:
+            eng.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
+            eng.upload_image(E.CELL_TYPES, scenes.full_fluid_types((d, h, w)))
+            eng.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((d, h, w), scenes.SEED_JACOBI))
+            eng.run_section("12a_clear_pressures_1")
+            eng.run_section("12b_clear_pressures_2")
+            eng.solve_pressure(iters)
+            return eng.download_image(E.PRESSURES_1)
+
+    full_step = True
+
+
+def cross_rank_checksum(solver, size, iters, dist_ctx, args, ranks):
+    """After the timed region: every rank sums the bits of its planes of PRESSURES_1 as the last timed step
+    left them; rank 0 compares the total with a one-rank run of the whole grid."""
+    import torch.distributed as dist
+    from fluid_amd import engine as E
+
+    mine = image_checksum(solver.download_image(E.PRESSURES_1))
+    parts = [None] * dist_ctx.world
+    dist.all_gather_object(parts, mine)
+    if dist_ctx.rank != 0:
+        return None
+    total = sum(p[0] for p in parts) % (1 << 64)
+    xor = 0
+    for p in parts:
+        xor ^= p[1]
+    out = {"image": "PRESSURES_1", "words": sum(p[2] for p in parts),
+           "sum_mod_2_64": total, "xor": xor}
+    try:
+        ref = image_checksum(ranks.one_rank_pressures_1(size, iters, dist_ctx.device, args))
+        out["one_rank"] = {"sum_mod_2_64": ref[0], "xor": ref[1], "words": ref[2]}
+        out["matches_one_rank_run"] = (ref[0], ref[1], ref[2]) == (total, xor, out["words"])
+    except Exception as exc:
+        out["one_rank"] = {"error": f"{type(exc).__name__}: {exc}"}
+        out["matches_one_rank_run"] = None
+    return out
+
+
+def slab_rank_main(args, ranks=None):
+    """One rank of `--gpus N` (N > 1, or FLUID_BENCH_FORCE_SLAB=1): the C++ slab driver's pressure step."""
+    import fluid_amd  # noqa: F401
+    from fluid_amd import slab as S
+
+    ranks = ranks or EngineRanks()
     size = grid_dims(args.grid)
     w, h, d = size
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_ctx = S.init_distributed(local_rank)
+    solver = ranks.make_solver(size, args.iters, dist_ctx, args)
+    result = solver.benchmark(args.steps, args.warmup)
+    halo = solver.stat(S.STAT_EFFECTIVE_HALO)
+    rccl_ranks = solver.stat(S.STAT_RCCL_RANKS)
+    result["exchanges_per_step"] = solver.stat(S.STAT_EXCHANGES) // max(
+        args.steps + args.warmup + (6 if result["halo_overlap"].get("probed") else 0), 1)
+    checksum = None
+    if not args.no_checksum:
+        try:
+            checksum = cross_rank_checksum(solver, size, args.iters, dist_ctx, args, ranks)
+        except Exception as exc:
+            checksum = {"error": f"{type(exc).__name__}: {exc}"}
+    solver.close()
+    full = None
+    if not args.no_full_step and ranks.full_step:
+        try:
+            full = slab_full_step_bench(size, args.iters, args.full_step_steps, dist_ctx,
+                                        overlap=(result.get("halo_overlap") or {}).get("used"))
+        except Exception as exc:  # the headline metric above must survive a failure here
+            full = {"error": f"{type(exc).__name__}: {exc}"}
+    if rank == 0:
+        cells = w * h * d
+        sweeps = args.steps * args.iters
+        wall = result["wall_s"]
+        kernel_ms = result["kernel_ms_per_sweep"]
+        local_cells = result["local_cells"]
+        achieved = (JACOBI_BYTES_PER_CELL * local_cells / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None
+        used = (result.get("halo_overlap") or {}).get("used")
+        out = {
+            "metric": "pressure_jacobi_iterations_per_sec",
+            "value": sweeps / wall,
+            "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"12_solve_pressure loop, {w}x{h}x{d} full-fluid grid, "
+                                   f"{args.iters} Jacobi iterations per step, Z slabs over "
+                                   f"{world} GPUs, halo exchange over RCCL Send/Recv",
+                       "grid": [w, h, d], "jacobi_iterations": args.iters,
+                       "parallelism": f"zslab{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": None,
+                         "kernel": "k12_canon2 (per GPU, on its slab; two sweeps per launch)"
+                                   if w % 4 == 0 and w <= 1024 else "k12_zmarch / k12_plain",
+                         "kernel_ms_per_sweep": kernel_ms,
+                         "note": "achieved = 13 B x local cells / kernel time per sweep (HIP events "
+                                 "on the engine's stream, MAX over ranks); ghost-plane recompute "
+                                 "of the deep halos is inside that time"},
+            "n_ranks_rccl": rccl_ranks,
+            "exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
+            "halo_exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
+            "halo_depth": halo,
+            "overlap_mode": OVERLAP_NAMES.get(used, used),
+            "halo_overlap": result.get("halo_overlap"),
+            "exchanges_per_step": result["exchanges_per_step"],
+            "checksum": checksum,
+            "cells_per_sec": cells * sweeps / wall,
+        }
+        if full is not None:
+            out["full_step"] = full
+        print(json.dumps(out), flush=True)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    size = grid_dims(args.grid)
+    w, h, d = size
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        if args.gpus < 1:
+            raise SystemExit("--gpus must be >= 1")
+        sys.exit(launch_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus "
-                             f"{args.gpus} ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment")
 
     import fluid_amd
     from fluid_amd import engine as E
@@ -400,61 +683,7 @@ def main():
         fluid_amd.build_engine()
 
     if world > 1 or os.environ.get("FLUID_BENCH_FORCE_SLAB") == "1":  # (the env var: tests only)
-        from fluid_amd import slab as S
-        dist_ctx = S.init_distributed(local_rank)
-        solver = S.SlabDriver.create_full_fluid(size, args.iters, dist_ctx)
-        solver.engine.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
-        result = solver.benchmark(args.steps, args.warmup)
-        halo = solver.stat(S.STAT_EFFECTIVE_HALO)
-        result["exchanges_per_step"] = solver.stat(S.STAT_EXCHANGES) // max(
-            args.steps + args.warmup + (6 if result["halo_overlap"].get("probed") else 0), 1)
-        solver.close()
-        full = None
-        if not args.no_full_step:
-            try:
-                full = slab_full_step_bench(size, args.iters, args.full_step_steps, dist_ctx,
-                                            overlap=(result.get("halo_overlap") or {}).get("used"))
-            except Exception as exc:  # the headline metric above must survive a failure here
-                full = {"error": f"{type(exc).__name__}: {exc}"}
-        if rank == 0:
-            cells = w * h * d
-            sweeps = args.steps * args.iters
-            wall = result["wall_s"]
-            kernel_ms = result["kernel_ms_per_sweep"]
-            local_cells = result["local_cells"]
-            achieved = JACOBI_BYTES_PER_CELL * local_cells / (kernel_ms * 1e-3) / 1e9
-            out = {
-                "metric": "pressure_jacobi_iterations_per_sec",
-                "value": sweeps / wall,
-                "unit": "iterations/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * wall / args.steps,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"12_solve_pressure loop, {w}x{h}x{d} full-fluid grid, "
-                                       f"{args.iters} Jacobi iterations per step, Z slabs over "
-                                       f"{world} GPUs, halo exchange over RCCL Send/Recv",
-                           "grid": [w, h, d], "jacobi_iterations": args.iters,
-                           "parallelism": f"zslab{world}"},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "k12_canon2 (per GPU, on its slab; two sweeps per launch)"
-                                       if w % 4 == 0 and w <= 1024 else "k12_zmarch / k12_plain",
-                             "kernel_ms_per_sweep": kernel_ms,
-                             "note": "achieved = 13 B x local cells / kernel time per sweep (HIP events "
-                                     "on the engine's stream, MAX over ranks); ghost-plane recompute "
-                                     "of the deep halos is inside that time"},
-                "halo_exchange_ms_per_sweep": result.get("exchange_ms_per_sweep"),
-                "halo_depth": halo,
-                "halo_overlap": result.get("halo_overlap"),
-                "cells_per_sec": cells * sweeps / wall,
-            }
-            if full is not None:
-                out["full_step"] = full
-            print(json.dumps(out), flush=True)
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        slab_rank_main(args)
         return
 
     # ------------------------------------------------------------------ single GPU

@@ -202,6 +202,7 @@ typedef enum fluid_slab_stat {
     FLUID_SLAB_STAT_EFFECTIVE_HALO = 5,   /* planes per exchange the Jacobi loop actually uses            */
     FLUID_SLAB_STAT_SAMPLER_HALO = 6,     /* ghost planes of VELOCITIES_1 currently exchanged for 07      */
     FLUID_SLAB_STAT_MIGRATE_ROUNDS = 7,   /* hand-over rounds that moved particles                        */
+    FLUID_SLAB_STAT_RCCL_RANKS = 8,       /* ncclCommCount of the attached communicator (0: no RCCL)      */
     FLUID_SLAB_STAT_COUNT
 } fluid_slab_stat;
 int fluid_slab_get_stat(fluid_slab* s, int stat, uint64_t* value);

@@ -31,3 +31,41 @@ def test_bench_multi_gpu_branch_with_one_rank():
     assert out["roofline"]["frac"] > 0
     assert "error" not in out["full_step"], out["full_step"]
     assert out["full_step"]["steps_per_sec"] > 0
+
+
+def _bare_env(**kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(kw)
+    return env
+
+
+def test_self_launched_rank_on_the_gpu():
+    """`bench.py --gpus 1 --spawn`: the launcher the driver's `--gpus N` call goes through (parent without
+    HIP, child processes with RANK / WORLD_SIZE set, rank 0's line relayed), with the one rank this box
+    can hold, through the slab branch."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--grid",
+                          "128", "--iters", "20", "--steps", "2", "--warmup", "1", "--no-full-step"],
+                         env=_bare_env(FLUID_BENCH_FORCE_SLAB="1"), capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["checksum"]["matches_one_rank_run"] is True, out["checksum"]
+    assert out["checksum"]["words"] == 128 ** 3
+    assert out["overlap_mode"] == "inline" and out["exchange_ms_per_sweep"] is not None
+
+
+def test_bare_gpus_2_on_a_one_gpu_box_fails_with_one_line():
+    import ctypes
+    n = ctypes.c_int(0)
+    # (counting devices in a child would be cleaner still; this process has the GPU anyway: pytest -m gpu)
+    if ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value >= 2:
+        pytest.skip("this box has two GPUs")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=_bare_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 2 and res.stdout == ""
+    lines = [ln for ln in res.stderr.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "1 GPU(s) visible" in lines[0] and "needs 2" in lines[0]

@@ -257,6 +257,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -305,6 +306,7 @@ const RcclApi* rccl_api(std::string& why) {
             api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
             api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+            api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
             api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
             api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
             api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
@@ -1139,6 +1141,8 @@ int fluid_slab_attach_rccl(fluid_slab* s, const void* id_bytes) {
     void* ptr = nullptr;
     HIPS(s, hipMalloc(&ptr, 4ull * RcclTransport::kScratchWords));
     t->scratch = static_cast<uint32_t*>(ptr);
+    int ranks = 0;  // what the communicator itself says its size is (bench.py reports it)
+    if (api->CommCount(t->comm, &ranks) == ncclSuccess) s->stats[FLUID_SLAB_STAT_RCCL_RANKS] = (uint64_t)ranks;
     s->tr = std::move(t);
     s->plans.clear();
     return FLUID_OK;
@@ -1186,6 +1190,8 @@ int fluid_slab_attach_rccl_self(fluid_slab* s, int has_lower, int has_upper) {
     void* ptr = nullptr;
     HIPS(s, hipMalloc(&ptr, 4ull * RcclTransport::kScratchWords));
     t->scratch = static_cast<uint32_t*>(ptr);
+    int ranks = 0;
+    if (api->CommCount(t->comm, &ranks) == ncclSuccess) s->stats[FLUID_SLAB_STAT_RCCL_RANKS] = (uint64_t)ranks;
     s->tr = std::move(t);
     s->loopback = true;
     s->lo = has_lower ? (int)s->rank : -1;

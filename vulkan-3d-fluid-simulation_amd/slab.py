@@ -28,7 +28,7 @@ from .params import PARAMS_BYTES, FluidParams, default_params
 OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH = 0, 1, 2
 OPT_OVERLAP, OPT_HALO_DEPTH, OPT_SAMPLER_HALO = 0, 1, 2
 (STAT_EXCHANGES, STAT_OVERLAPPED, STAT_MIGRATED, STAT_SAMPLER_RERUNS, STAT_SAMPLER_WIDE,
- STAT_EFFECTIVE_HALO, STAT_SAMPLER_HALO, STAT_MIGRATE_ROUNDS) = range(8)
+ STAT_EFFECTIVE_HALO, STAT_SAMPLER_HALO, STAT_MIGRATE_ROUNDS, STAT_RCCL_RANKS) = range(9)
 XFER_SEND, XFER_HOST_MEMORY = 1, 2
 RCCL_ID_BYTES = 128
 LOOP_PART_EDGES, LOOP_PART_INTERIOR = 1, 2
@@ -424,6 +424,8 @@ class SlabDriver:
             msg = self._lib.fluid_slab_last_error(None)
             self._h = C.c_void_p()
             raise SlabError(rc, msg.decode() if msg else "fluid_slab_create failed")
+        if self._backend is not None:
+            self._backend.error = None   # creation ignores a backend without a sampler halo; do not keep its raise
         z0, n = C.c_uint32(), C.c_uint32()
         self._lib.fluid_slab_get_slab(self._h, C.byref(z0), C.byref(n))
         self.slab = (int(z0.value), int(n.value))
