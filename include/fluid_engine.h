@@ -326,10 +326,11 @@ int fluid_image_plane_ptr(fluid_ctx* ctx, int image_id, int32_t plane, void** de
 /* The loop section in explicit form, for callers that must act between launches (halo exchange):
  *   begin   : build the solver's working data from CELL_TYPES / DIVERGENCES / PRESSURES_1
  *             (iterate 0 -> working buffer 0)
- *   advance : 1 sweep, or 2 sweeps in one pass over HBM where fluid_pressure_loop_max_sweeps() says
- *             2; `keep_intermediate` = also keep the odd iterate of a pair (needed for the last pair
- *             of an even-length loop); *written_buffer = working buffer (0..2) now holding the newest
- *             iterate
+ *   advance : 1 sweep, or 2 or 3 sweeps in one pass over HBM, up to fluid_pressure_loop_max_sweeps()
+ *             (3 on grids up to 512 cells wide, 2 on wider ones, 1 with FLUID_OPT_JACOBI_FUSE = 1);
+ *             `keep_intermediate` = also keep the iterate before the newest one (needed by the last
+ *             launch of a loop: PRESSURES_1 / _2 end with the last even / odd iterate);
+ *             *written_buffer = working buffer (0..2) now holding the newest iterate
  *   end     : write the last two iterates into the water cells of PRESSURES_1 (even) / PRESSURES_2 (odd)
  * begin; advance...; end equals fluid_run_section_loop(FLUID_SEC_12_SOLVE_PRESSURE, N) for the same
  * number of sweeps.
@@ -377,6 +378,10 @@ int fluid_pressure_loop_end(fluid_ctx* ctx);
  * enqueueing EDGES (pass after it). */
 #define FLUID_LOOP_PART_EDGES 1
 #define FLUID_LOOP_PART_INTERIOR 2
+/* ..._part_n: the same for a pass of `sweeps` (2 or 3) sweeps — the interior of the first pass after an
+ * exchange is then [sweeps, z_count - sweeps); ..._part is ..._part_n with two. */
+int fluid_pressure_loop_advance_part_n(fluid_ctx* ctx, uint32_t sweeps, int keep_intermediate, int part,
+                                       int32_t interior_begin, int32_t interior_end, int* written_buffer);
 int fluid_pressure_loop_advance_part(fluid_ctx* ctx, int keep_intermediate, int part,
                                      int32_t interior_begin, int32_t interior_end,
                                      int* written_buffer);
@@ -515,8 +520,9 @@ typedef enum fluid_option {
                                    /* z-marching with 2/4/1 rows per wavefront.  Loop section: 1-4   */
                                    /* = that kernel once per sweep on the images; 0/5/6/7 = working- */
                                    /* buffer fast path with 1/2/4/1 rows per wavefront               */
-    FLUID_OPT_JACOBI_FUSE = 1,     /* loop section: 0 = two sweeps per pass over HBM (default),     */
-                                   /* 1 = one kernel launch per sweep                               */
+    FLUID_OPT_JACOBI_FUSE = 1,     /* loop section: 0 = several sweeps per pass over HBM (default: three */
+                                   /* on grids up to 512 cells wide, two on wider ones), 1 = one kernel   */
+                                   /* launch per sweep, 2 = at most two sweeps per pass, 3 = as 0        */
     FLUID_OPT_STEP_FUSION = 2,     /* fluid_run_step: 0 = sections 04+05, 07+08 and 09+10+11 run as   */
                                    /* grouped passes (default; every image ends the step with the   */
                                    /* bits the section list leaves, intermediates are not stored),  */

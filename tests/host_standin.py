@@ -247,10 +247,21 @@ class HostGlobalCompute:
 
     def loop_advance(self, k, sweeps, keep_mid, part=None, interior=None):
         assert k == self.k and part is None   # max_halo 8 on slabs of >= 17 planes would split: not here
-        if sweeps == 2:
+        if sweeps >= 2:   # a pass of 2 or 3 sweeps: only the last iterate (and, kept, the one before) stays
             dst = self._other(self.cur, self.cur)
             mid = self._other(self.cur, dst)
-            self._sweep(self.cur, mid)
+            src = self.cur
+            if sweeps == 3:
+                if not hasattr(self, "_scratch"):
+                    self._scratch = np.zeros_like(self.work[0])
+                self.work.append(self._scratch)
+                self._sweep(src, 3)
+                self.work.pop()
+                self.work.append(self._scratch)
+                self._sweep(3, mid)
+                self.work.pop()
+            else:
+                self._sweep(src, mid)
             self._sweep(mid, dst)
             self.prev = mid if keep_mid else -1
             self.cur = dst
@@ -348,12 +359,22 @@ class HostSlabCompute:
     def _other(self, a, b):
         return next(i for i in range(3) if i not in (a, b))
 
-    def _split_pass(self, keep_mid, part, interior):
+    def _fused_into(self, sweeps, t_mid, t_dst):
+        """`sweeps` (2 or 3) oracle sweeps from the newest iterate: the last one into t_dst, the one before into
+        t_mid."""
+        src = self.work[self.cur]
+        if sweeps == 3:
+            first = torch.zeros_like(src)
+            self.sweep_fn(src, first)
+            src = first
+        self.sweep_fn(src, t_mid)
+        self.sweep_fn(t_mid, t_dst)
+
+    def _split_pass(self, sweeps, keep_mid, part, interior):
         dst = self._other(self.cur, self.cur)
         mid = self._other(self.cur, dst)
         t_mid, t_dst = self.work[mid].clone(), self.work[dst].clone()
-        self.sweep_fn(self.work[self.cur], t_mid)
-        self.sweep_fn(t_mid, t_dst)
+        self._fused_into(sweeps, t_mid, t_dst)
         n = self.dl + 2 * self.GW
         a = min(max(interior[0] + self.GW, 0), n)
         b = min(max(interior[1] + self.GW, a), n)
@@ -367,20 +388,19 @@ class HostSlabCompute:
         self._part_done = None
         self.prev = mid if keep_mid else -1
         self.cur = dst
-        self.k += 2
+        self.k += sweeps
         return dst
 
     def loop_advance(self, k, sweeps, keep_mid, part=None, interior=None):
         assert k == self.k
         if part is not None:
-            assert sweeps == 2
-            return self._split_pass(keep_mid, part, interior)
+            assert sweeps >= 2
+            return self._split_pass(sweeps, keep_mid, part, interior)
         assert self._part_done is None
-        if sweeps == 2:
+        if sweeps >= 2:
             dst = self._other(self.cur, self.cur)
             mid = self._other(self.cur, dst)
-            self.sweep_fn(self.work[self.cur], self.work[mid])
-            self.sweep_fn(self.work[mid], self.work[dst])
+            self._fused_into(sweeps, self.work[mid], self.work[dst])
             self.prev = mid if keep_mid else -1
             self.cur = dst
         else:

@@ -535,14 +535,21 @@ def test_pressure_fast_path_invalidation():
 
 
 @pytest.mark.parametrize("size", [(64, 40, 24), (256, 13, 9), (512, 19, 35), (260, 6, 5), (768, 7, 6),
-                                  (1024, 5, 4), (8, 8, 8), (1280, 6, 5)])
-@pytest.mark.parametrize("iters", [2, 3, 4, 5, 6, 7, 8, 12])
-def test_pressure_fused_pairs_match_oracle(size, iters):
-    """Two sweeps per pass (kernels_pressure_fused.h): every pairing case of the loop schedule —
-    odd / even number of pairs, odd tail — on grids with 1, 2 and 4 x-tiles, ragged row groups and
+                                  (1024, 5, 4), (8, 8, 8), (1280, 6, 5), (256, 50, 11), (512, 29, 7)])
+@pytest.mark.parametrize("iters", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("fuse", [0, 2])
+def test_pressure_fused_pairs_match_oracle(size, iters, fuse):
+    """Several sweeps per pass (kernels_pressure_fused.h: two; kernels_pressure_fused3.h: three, the default
+    on grids up to 512 cells wide; fuse = 2 limits the loop to pairs): every case of the loop schedule — every
+    residue of the sweep count modulo 3 and 2, so launches of three followed by one or two of two, a kept
+    next-to-last iterate from either kind, odd tails — on grids with 1, 2 and 4 x-tiles, ragged row groups and
     z chunks, random cell types with no solid shell."""
     st = random_state(size, seed=iters, solid_walls=False, water_fraction=0.6)
     with make_engine(st) as eng:
+        eng.set_option(E.OPT_JACOBI_FUSE, fuse)
+        w, _, d = size
+        assert eng.pressure_loop_max_sweeps() == (3 if fuse == 0 and w % 4 == 0 and w <= 512 and d >= 3 else
+                                                  2 if w % 4 == 0 and w <= 1024 and d >= 2 else 1)
         for name in ("12a_clear_pressures_1", "12b_clear_pressures_2"):
             eng.run_section(name)
             st.run_section(name)
@@ -569,9 +576,10 @@ def test_pressure_fused_streaming_store_kernels_match_oracle():
     code = (
         "import sys; sys.path[:0] = [%r, %r]\n"
         "import test_engine_parity_gpu as T\n"
-        "for size in [(512, 19, 35), (768, 7, 6), (1024, 5, 4)]:\n"
-        "    for iters in (2, 5, 8):\n"
-        "        T.test_pressure_fused_pairs_match_oracle(size, iters)\n"
+        "for size in [(512, 19, 35), (768, 7, 6), (1024, 5, 4), (512, 29, 7)]:\n"
+        "    for iters in (2, 3, 5, 8, 9):\n"
+        "        for fuse in (0, 2):\n"
+        "            T.test_pressure_fused_pairs_match_oracle(size, iters, fuse)\n"
         "print('streaming ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
     env = dict(os.environ, FLUID_FUSED_NT="1")
     out = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
@@ -596,32 +604,38 @@ def test_pressure_fused_sparse_scene_and_bricks():
 
 
 @pytest.mark.parametrize("size", [(64, 24, 40), (512, 9, 21)])
-def test_pressure_split_passes_equal_whole_passes(size):
-    """fluid_pressure_loop_advance_part: a pass as EDGES + INTERIOR launches, in either order, equals
-    the whole pass (and the oracle); misuse is reported."""
+@pytest.mark.parametrize("sweeps", [2, 3])
+def test_pressure_split_passes_equal_whole_passes(size, sweeps):
+    """fluid_pressure_loop_advance_part(_n): a pass of two or three sweeps as EDGES + INTERIOR launches, in
+    either order, equals the whole pass (and the oracle); misuse is reported."""
     st = random_state(size, seed=9, iters=8)
     d = size[2]
     with make_engine(st) as eng:
         eng.pressure_loop_begin()
+        assert eng.pressure_loop_max_sweeps() == 3
         edges, interior = eng.LOOP_PART_EDGES, eng.LOOP_PART_INTERIOR
         # pass 1: edges first; pass 2: interior first; pass 3: interior covers everything; pass 4:
-        # empty interior, keeps the odd iterate (last pair of an 8-sweep loop)
+        # empty interior, keeps the next-to-last iterate (last launch of the loop)
         plans = [(False, edges, 5, d - 5), (False, interior, 2, d - 2),
                  (False, interior, -2 ** 31, 2 ** 31 - 1), (True, edges, 7, 7)]
         for keep, first, lo, hi in plans:
             other = interior if first == edges else edges
-            w1 = eng.pressure_loop_advance_part(keep, first, lo, hi)
+            w1 = eng.pressure_loop_advance_part(keep, first, lo, hi, sweeps)
             with pytest.raises(fluid_amd.FluidEngineError, match="other part"):
-                eng.pressure_loop_advance_part(keep, first, lo, hi)       # same part twice
+                eng.pressure_loop_advance_part(keep, first, lo, hi, sweeps)       # same part twice
             with pytest.raises(fluid_amd.FluidEngineError, match="other part"):
-                eng.pressure_loop_advance_part(not keep, other, lo, hi)  # other arguments
+                eng.pressure_loop_advance_part(not keep, other, lo, hi, sweeps)  # other arguments
+            with pytest.raises(fluid_amd.FluidEngineError, match="other part"):
+                eng.pressure_loop_advance_part(keep, other, lo, hi, 5 - sweeps)  # another number of sweeps
             with pytest.raises(fluid_amd.FluidEngineError, match="half done"):
                 eng.pressure_loop_advance(2, keep)
             with pytest.raises(fluid_amd.FluidEngineError, match="half done"):
                 eng.pressure_loop_end()
-            assert eng.pressure_loop_advance_part(keep, other, lo, hi) == w1
+            assert eng.pressure_loop_advance_part(keep, other, lo, hi, sweeps) == w1
+        with pytest.raises(fluid_amd.FluidEngineError, match="cannot advance by 4"):
+            eng.pressure_loop_advance(4, False)
         eng.pressure_loop_end()
-        st.solve_pressure(8)
+        st.solve_pressure(4 * sweeps)
         assert_state_equal(eng, st, fields=["pressures_1", "pressures_2"], ctx="split passes: ")
 
 
@@ -783,20 +797,21 @@ def test_pressure_residual_readout(size):
 
 
 def test_pressure_512cubed_default_equals_plain_and_window_matches_oracle():
-    """512^3 full-fluid grid (BASELINE config C4, the size the metric is quoted on), 6 sweeps: the
-    default path (two sweeps per pass, division-free quotient, chunked z march) agrees bit for bit with
-    the one-thread-per-cell kernel on the images everywhere, and a 20-plane window recomputed by the
-    oracle matches outside its dependence cone."""
-    n, iters = 512, 6
+    """512^3 full-fluid grid (BASELINE config C4, the size the metric is quoted on), 8 sweeps: the
+    default path (launches of 3 + 3 + 2 sweeps per pass, division-free quotient, chunked z march) and the
+    pairs-only schedule agree bit for bit with the one-thread-per-cell kernel on the images everywhere, and
+    a 20-plane window recomputed by the oracle matches outside its dependence cone."""
+    n, iters = 512, 8
     p = default_params(n, n, n, 0)
     shape = (n, n, n)
     t = scenes.full_fluid_types(shape)
     div = scenes.full_fluid_divergence(shape)
     sums = {}
     keep = None
-    for variant in (1, 0):
+    for variant, fuse in ((1, 0), (0, 0), (0, 2)):
         with fluid_amd.FluidEngine(p, particle_capacity=0) as eng:
             eng.set_option(E.OPT_PRESSURE_KERNEL, variant)
+            eng.set_option(E.OPT_JACOBI_FUSE, fuse)
             eng.upload_image(E.CELL_TYPES, t)
             eng.upload_image(E.DIVERGENCES, div)
             eng.run_section("12a_clear_pressures_1")
@@ -806,8 +821,8 @@ def test_pressure_512cubed_default_equals_plain_and_window_matches_oracle():
         if keep is None:
             keep = (p1, p2)
         else:
-            assert_bit_equal(p1, keep[0], "512^3 P1 default vs plain")
-            assert_bit_equal(p2, keep[1], "512^3 P2 default vs plain")
+            assert_bit_equal(p1, keep[0], f"512^3 P1 default (fuse option {fuse}) vs plain")
+            assert_bit_equal(p2, keep[1], f"512^3 P2 default (fuse option {fuse}) vs plain")
         sums[variant] = int(p1.view(np.uint32).astype(np.uint64).sum())
     z0, zc = 300, 20
     pw = default_params(n, n, zc, 0)

@@ -81,7 +81,7 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
     b1, b2 = pressures()
     thinnest = min(m for _, m in S.partition_z(d, world))
     eff = drv.stat(S.STAT_EFFECTIVE_HALO)
-    assert eff == max(1, min(halo, 8, thinnest) - (min(halo, 8, thinnest) % 2 if max_sweeps >= 2 and
+    assert eff == max(1, min(halo, 8, thinnest) - (min(halo, 8, thinnest) % 2 if max_sweeps == 2 and
                                                     min(halo, 8, thinnest) >= 2 else 0))
     if max_sweeps >= 2 and eff >= 4 and thinnest > 2 * eff:
         assert drv.stat(S.STAT_OVERLAPPED) > 0  # the split-pass schedule ran
@@ -116,6 +116,12 @@ def _worker(rank, world, port, size, iters, seed, max_sweeps, halo, out_dir):
     (2, (12, 10, 20), 13, 2, 4),   # slabs of 10 planes, halo 4: exchanges overlap split passes
     (3, (8, 9, 30), 18, 2, 4),     # three ranks (the middle one has two neighbours), overlapped
     (2, (8, 8, 40), 20, 2, 8),     # halo 8 on slabs of 20 planes, overlapped
+    # three sweeps per pass (kernels_pressure_fused3.h): launches of 3 + 3 + 2 between two exchanges of 8
+    (2, (12, 10, 16), 13, 3, 8),   # slabs of 8 planes, no split passes; 13 = 3 + 3 + 2 | 3 + 2, then 14
+    (2, (8, 8, 40), 20, 3, 8),     # overlapped: the pass before an exchange is a pair, the one after a triple
+    (3, (8, 9, 30), 18, 3, 6),     # halo 6: two triples per exchange, both split
+    (3, (8, 9, 20), 9, 3, 3),      # halo 3: one triple per exchange
+    (2, (8, 8, 40), 7, 3, 7),      # an odd halo: 3 + 3, one plane left over
 ])
 def test_slab_solver_equals_single_domain_oracle(world, size, iters, max_sweeps, halo, tmp_path):
     import torch.multiprocessing as mp

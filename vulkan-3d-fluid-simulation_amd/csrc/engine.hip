@@ -194,6 +194,7 @@ struct fluid_ctx {
     bool edges_pending = false;
     int loop_part_done = 0;      // FUSED_EDGES / FUSED_INTERIOR: that half of a split pass is launched
     bool loop_part_keep = false;
+    uint32_t loop_part_sweeps = 2;
     int loop_part_lo = 0, loop_part_hi = 0;
 
     bool timing = false;
@@ -737,16 +738,16 @@ int launch_work_sweep(fluid_ctx* c, int src, int dst, int zlo = 0, int zhi = -1)
     return FLUID_OK;
 }
 
-// two sweeps in one pass (kernels_pressure_fused.h): work[src] = iterate j -> work[dst] = iterate
-// j+2, and iterate j+1 -> work[mid] when mid >= 0.  Whole-grid contexts only.
+// two or three sweeps in one pass (kernels_pressure_fused.h, kernels_pressure_fused3.h): work[src] = iterate j
+// -> work[dst] = iterate j + sweeps, and iterate j + sweeps - 1 -> work[mid] when mid >= 0.
 int launch_fused(fluid_ctx* c, int src, int dst, int mid, int part = FUSED_WHOLE, int part_lo = 0,
-                 int part_hi = 0, hipStream_t stream = nullptr) {
+                 int part_hi = 0, hipStream_t stream = nullptr, int sweeps = 2) {
     const bool lo = c->g.z0 > 0, hi = c->g.z0 + c->g.Dl < c->g.Dg;  // neighbouring slabs
-    HIP_TRY(c, k12_launch_canon2(stream ? stream : c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
-                                 mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g,
-                                 oob_value(c), lo ? c->loop_halo : 0, hi ? c->loop_halo : 0,
-                                 lo ? c->loop_aux_halo : 0, hi ? c->loop_aux_halo : 0,
-                                 c->box, part, part_lo, part_hi));
+    auto* launch = sweeps == 3 ? &k12_launch_canon3 : &k12_launch_canon2;
+    HIP_TRY(c, launch(stream ? stream : c->stream, c->mask0(), c->rhs0(), c->work0(src), c->work0(dst),
+                      mid >= 0 ? c->work0(mid) : nullptr, c->bricks(), c->g, oob_value(c),
+                      lo ? c->loop_halo : 0, hi ? c->loop_halo : 0, lo ? c->loop_aux_halo : 0,
+                      hi ? c->loop_aux_halo : 0, c->box, part, part_lo, part_hi));
     HIP_TRY(c, hipGetLastError());
     return FLUID_OK;
 }
@@ -799,16 +800,18 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int
     // a pass in two launches (FUSED_EDGES / FUSED_INTERIOR, either order): the second one commits
     bool commit = true;
     if (part != FUSED_WHOLE) {
-        if (sweeps != 2)
-            return c->fail(FLUID_ERR_INVALID_ARG, "only a two-sweep pass can be split into parts");
+        if (sweeps < 2)
+            return c->fail(FLUID_ERR_INVALID_ARG, "only a pass of two or three sweeps can be split into parts");
         if (c->loop_part_done == 0) {
             c->loop_part_done = part;
+            c->loop_part_sweeps = sweeps;
             c->loop_part_keep = keep_mid;
             c->loop_part_lo = part_lo;
             c->loop_part_hi = part_hi;
             commit = false;
         } else if (c->loop_part_done == part || c->loop_part_keep != keep_mid ||
-                   c->loop_part_lo != part_lo || c->loop_part_hi != part_hi) {
+                   c->loop_part_lo != part_lo || c->loop_part_hi != part_hi ||
+                   c->loop_part_sweeps != sweeps) {
             return c->fail(FLUID_ERR_INVALID_ARG,
                            "the second part of a split pass must be the other part with the same "
                            "arguments");
@@ -818,7 +821,7 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int
     } else if (c->loop_part_done != 0) {
         return c->fail(FLUID_ERR_INVALID_ARG, "a split pass is half done: launch its other part");
     }
-    if (sweeps == 2) {
+    if (sweeps >= 2) {
         const int dst = other_buffer(cur, cur);
         const int mid = keep_mid ? other_buffer(cur, dst) : -1;
         rc = ensure_background(c, dst);
@@ -836,7 +839,7 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int
                 where = c->edge_stream;
             }
         }
-        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid, part, part_lo, part_hi, where);
+        if (rc == FLUID_OK) rc = launch_fused(c, cur, dst, mid, part, part_lo, part_hi, where, (int)sweeps);
         if (where && rc == FLUID_OK) {
             HIP_TRY(c, hipEventRecord(c->ev_edges_done, c->edge_stream));
             c->edges_pending = true;
@@ -849,8 +852,9 @@ int loop_advance(fluid_ctx* c, uint32_t sweeps, bool keep_mid, int* written, int
         }
         c->loop_prev = mid;
         c->loop_cur = dst;
-        c->loop_k += 2;
-        c->loop_halo = std::max(0, std::min(c->loop_halo - 2, c->loop_aux_halo - 1));
+        c->loop_k += sweeps;
+        // every sweep consumes a ghost plane of the iterate, every sweep but the first one of mask / b_i
+        c->loop_halo = std::max(0, std::min(c->loop_halo - (int)sweeps, c->loop_aux_halo - ((int)sweeps - 1)));
     } else {
         const int dst = other_buffer(cur, c->loop_prev >= 0 ? c->loop_prev : cur);
         rc = ensure_background(c, dst);
@@ -877,22 +881,41 @@ int loop_end(fluid_ctx* c) {
 bool fuse_enabled(const fluid_ctx* c) {
     return k12_canon2_supports(c->g) && c->opt[FLUID_OPT_JACOBI_FUSE] != 1;
 }
+// sweeps per pass over HBM the loop section may use on this context: a property of the grid and the options
+// only (the ranks of a Z-slab run must come to the same number), FLUID_FUSED_T = 2 / 3 in the environment
+// overrides the automatic choice (A/B runs)
+int max_sweeps_per_pass(const fluid_ctx* c) {
+    if (!fuse_enabled(c)) return 1;
+    static const int forced = [] {
+        const char* e = getenv("FLUID_FUSED_T");
+        return e ? atoi(e) : 0;
+    }();
+    const int64_t opt = c->opt[FLUID_OPT_JACOBI_FUSE];
+    const int want = opt == 2 ? 2 : (opt == 3 ? 3 : (forced == 2 || forced == 3 ? forced : 3));
+    return want == 3 && k12_canon3_supports(c->g) ? 3 : 2;
+}
+// sweeps of the next launch of a loop with `left` sweeps to go, at most `most` (the ghost planes at hand) per
+// launch: as many threes as possible, no single sweep at the end unless the loop has only one (4 = 2 + 2)
+uint32_t next_launch_sweeps(uint32_t left, uint32_t most) {
+    if (left <= 1 || most <= 1) return std::min<uint32_t>(left, 1);
+    if (most == 2 || left == 2 || left == 4) return 2;
+    return 3;
+}
 
 // FlowLoopPushConstantSection on working buffers (single context, no halo exchange)
 int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
     if (iterations == 0) return FLUID_OK;
     int rc = loop_begin(c);
-    const bool fuse = fuse_enabled(c) && !c->is_slab;  // a slab needs its halos between launches
+    // a slab needs its halos between launches
+    const uint32_t most = c->is_slab ? 1u : (uint32_t)max_sweeps_per_pass(c);
     // shaping the launches to the water costs one stream synchronisation per rebuilt mask; a caller that
     // wants fluid_run_step to stay fully asynchronous turns it off (FLUID_OPT_LAUNCH_BOX = 1)
-    if (rc == FLUID_OK && fuse && iterations >= 16 && c->opt[FLUID_OPT_LAUNCH_BOX] == 0)
+    if (rc == FLUID_OK && most >= 2 && iterations >= 16 && c->opt[FLUID_OPT_LAUNCH_BOX] == 0)
         rc = refresh_box(c);
     while (rc == FLUID_OK && c->loop_k < iterations) {
         const uint32_t left = iterations - c->loop_k;
-        if (fuse && left >= 2)
-            rc = loop_advance(c, 2, left == 2, nullptr);
-        else
-            rc = loop_advance(c, 1, false, nullptr);
+        const uint32_t sweeps = next_launch_sweeps(left, most);
+        rc = loop_advance(c, sweeps, sweeps >= 2 && left == sweeps, nullptr);
     }
     if (rc) return rc;
     return loop_end(c);
@@ -2021,7 +2044,7 @@ int fluid_pressure_loop_begin(fluid_ctx* c) {
 
 int fluid_pressure_loop_max_sweeps(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
-    return fuse_enabled(c) ? 2 : 1;
+    return max_sweeps_per_pass(c);
 }
 
 int fluid_pressure_loop_available(fluid_ctx* c) {
@@ -2033,7 +2056,7 @@ int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermed
                                 int* written_buffer) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
-    if (sweeps != 1 && !(sweeps == 2 && fuse_enabled(c)))
+    if (sweeps == 0 || (int)sweeps > max_sweeps_per_pass(c))
         return c->fail(FLUID_ERR_INVALID_ARG, "cannot advance by %u sweeps in one launch", sweeps);
     HIP_TRY(c, hipSetDevice(c->device));
     SectionTimer tm{c};
@@ -2041,18 +2064,19 @@ int fluid_pressure_loop_advance(fluid_ctx* c, uint32_t sweeps, int keep_intermed
     if (rc) return rc;
     rc = loop_advance(c, sweeps, keep_intermediate != 0, written_buffer);
     int rc2 = tm.end();
-    if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && sweeps == 2)
-        c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += 1;  // count sweeps
+    if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && sweeps >= 2)
+        c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += sweeps - 1;  // count sweeps
     return rc ? rc : rc2;
 }
 
-int fluid_pressure_loop_advance_part(fluid_ctx* c, int keep_intermediate, int part,
-                                     int32_t interior_begin, int32_t interior_end,
-                                     int* written_buffer) {
+int fluid_pressure_loop_advance_part_n(fluid_ctx* c, uint32_t sweeps, int keep_intermediate, int part,
+                                       int32_t interior_begin, int32_t interior_end, int* written_buffer) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     if (!c->loop_open) return c->fail(FLUID_ERR_INVALID_ARG, "fluid_pressure_loop_begin first");
     if (!fuse_enabled(c))
-        return c->fail(FLUID_ERR_UNSUPPORTED, "split passes need the two-sweeps-per-pass kernel");
+        return c->fail(FLUID_ERR_UNSUPPORTED, "split passes need the several-sweeps-per-pass kernels");
+    if (sweeps < 2 || (int)sweeps > max_sweeps_per_pass(c))
+        return c->fail(FLUID_ERR_INVALID_ARG, "a split pass of %u sweeps", sweeps);
     if (part != FLUID_LOOP_PART_EDGES && part != FLUID_LOOP_PART_INTERIOR)
         return c->fail(FLUID_ERR_INVALID_ARG, "unknown part %d", part);
     if (interior_end < interior_begin)
@@ -2061,11 +2085,21 @@ int fluid_pressure_loop_advance_part(fluid_ctx* c, int keep_intermediate, int pa
     SectionTimer tm{c};
     int rc = tm.begin(FLUID_SEC_12_SOLVE_PRESSURE);
     if (rc) return rc;
-    rc = loop_advance(c, 2, keep_intermediate != 0, written_buffer,
+    const bool first = c->loop_part_done == 0;
+    rc = loop_advance(c, sweeps, keep_intermediate != 0, written_buffer,
                       part == FLUID_LOOP_PART_EDGES ? FUSED_EDGES : FUSED_INTERIOR, interior_begin,
                       interior_end);
-    int rc2 = tm.end();  // two launches = two timer calls = the pass's two sweeps in sec_calls
+    int rc2 = tm.end();  // two launches = two timer calls: the first two sweeps of the pass in sec_calls
+    if (c->timing && rc == FLUID_OK && rc2 == FLUID_OK && !first && sweeps > 2)
+        c->sec_calls[FLUID_SEC_12_SOLVE_PRESSURE] += sweeps - 2;
     return rc ? rc : rc2;
+}
+
+int fluid_pressure_loop_advance_part(fluid_ctx* c, int keep_intermediate, int part,
+                                     int32_t interior_begin, int32_t interior_end,
+                                     int* written_buffer) {
+    return fluid_pressure_loop_advance_part_n(c, 2, keep_intermediate, part, interior_begin, interior_end,
+                                              written_buffer);
 }
 
 int fluid_pressure_loop_edge_stream(fluid_ctx* c, void** hip_stream) {

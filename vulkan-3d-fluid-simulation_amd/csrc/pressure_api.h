@@ -79,6 +79,13 @@ hipError_t k12_launch_canon2(hipStream_t s, const uint8_t* mask, const float* rh
 // the output planes [part_lo, part_hi) (clipped to the pass's output range), FUSED_EDGES the rest
 enum { FUSED_WHOLE = 0, FUSED_EDGES = 1, FUSED_INTERIOR = 2 };
 bool k12_canon2_supports(const GridK& g);
+// three sweeps per pass (kernels_pressure_fused3.h): same arguments; a launch consumes three ghost planes of the
+// input and two of mask / b_i per side.  Grids up to 512 cells wide.
+hipError_t k12_launch_canon3(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
+                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
+                             float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
+                             const ActiveBox& box, int part = 0, int part_lo = 0, int part_hi = 0);
+bool k12_canon3_supports(const GridK& g);
 // one red-black SOR iteration (colour 0 then colour 1) in one pass over HBM: work[src] -> work[dst]
 hipError_t k12_launch_canon2_sor(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                                  float* pout, const uint8_t* bricks, const GridK& g, float p_oob,

@@ -4,9 +4,11 @@
 #pragma once
 
 #include "kernels_pressure_fused.h"
+#include "kernels_pressure_fused3.h"
 #include "pressure_api.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -21,12 +23,12 @@ namespace fluid {
 // Estimate the makespan of every candidate chunk length by dealing the tiles (cost = planes + 2
 // pipeline steps + a fixed start-up) to the CUs in launch order, and take the best.  Host
 // arithmetic, cached per geometry.
-static inline int pick_zchunk(int row_groups, int depth, int cus) {
+static inline int pick_zchunk(int row_groups, int depth, int cus, int sweeps = 2) {
     // cached per geometry (a slab loop alternates between a few depths; the model costs ~1 ms)
-    static std::map<std::tuple<int, int, int>, int> cache;
+    static std::map<std::tuple<int, int, int, int>, int> cache;
     static std::mutex cache_mutex;  // contexts of different host threads share this table
     std::lock_guard<std::mutex> lock(cache_mutex);
-    const auto key = std::make_tuple(row_groups, depth, cus);
+    const auto key = std::make_tuple(row_groups, depth, cus, sweeps);
     const auto hit = cache.find(key);
     if (hit != cache.end()) return hit->second;
     const double startup = 3.0;
@@ -41,7 +43,7 @@ static inline int pick_zchunk(int row_groups, int depth, int cus) {
         double makespan = 0.0;
         for (int z = 0; z < nz; z++) {
             const int planes = std::min(zc, depth - z * zc);
-            const double cost = planes + 2 + startup;
+            const double cost = planes + 2 * (sweeps - 1) + startup;  // pipeline steps of a T-sweep march
             for (int y = 0; y < row_groups; y++) {
                 std::pop_heap(busy.begin(), busy.end(), cmp);
                 busy.back() += cost;
@@ -72,11 +74,11 @@ struct XcdPlan {
     bool on;
     int start[9];
 };
-static inline XcdPlan xcd_plan(int by, int nz_lo, int nz, int zchunk, int seg1, int seg2, int cus) {
-    static std::map<std::tuple<int, int, int, int, int, int, int>, XcdPlan> cache;
+static inline XcdPlan xcd_plan(int by, int nz_lo, int nz, int zchunk, int seg1, int seg2, int cus, int sweeps = 2) {
+    static std::map<std::tuple<int, int, int, int, int, int, int, int>, XcdPlan> cache;
     static std::mutex cache_mutex;
     std::lock_guard<std::mutex> lock(cache_mutex);
-    const auto key = std::make_tuple(by, nz_lo, nz, zchunk, seg1, seg2, cus);
+    const auto key = std::make_tuple(by, nz_lo, nz, zchunk, seg1, seg2, cus, sweeps);
     const auto hit = cache.find(key);
     if (hit != cache.end()) return hit->second;
     const int U = by * nz;
@@ -85,7 +87,7 @@ static inline XcdPlan xcd_plan(int by, int nz_lo, int nz, int zchunk, int seg1, 
     for (int tz = 0, u = 0; tz < nz; tz++) {
         const int planes = tz < nz_lo ? std::min(zchunk, seg1 - tz * zchunk)
                                       : std::min(zchunk, seg2 - (tz - nz_lo) * zchunk);
-        for (int y = 0; y < by; y++, u++) total += cost[u] = planes + 5;  // pick_zchunk's cost of a workgroup
+        for (int y = 0; y < by; y++, u++) total += cost[u] = planes + 3 + 2 * (sweeps - 1);  // pick_zchunk's cost of a workgroup
     }
     auto makespan = [&](int u0, int u1, int step, int n_cus) {  // in-order list scheduling, as in pick_zchunk
         std::vector<long> busy(std::max(1, n_cus), 0);
@@ -182,25 +184,41 @@ struct FusedLaunchArgs {
 template <int NT, int RG, bool KEEP>
 hipError_t k12_launch_streaming(const FusedLaunchArgs& a);
 
-template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false>
+// the geometry of the T-sweeps-per-pass kernel (T = 2: k12_canon2; T = 3: k12_canon_t)
+template <int NT, int RG, int T>
+struct FusedShape {
+    using G = FusedGeom<NT, RG>;
+};
+template <int NT, int RG>
+struct FusedShape<NT, RG, 3> {
+    using G = FusedGeomT<NT, RG, 3>;
+};
+// the kernel with streaming stores (three sweeps: k12_canon_t<NT, false, RG, 3, KEEP, true>), pressure_fused3.hip
+template <int NT, int RG, bool KEEP>
+hipError_t k12_launch_streaming3(const FusedLaunchArgs& a);
+
+template <int NT, bool WIN, int RG, bool KEEP, bool SOR = false, int T = 2>
 static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g,
                             float p_oob, const FusedRange& rg, const ActiveBox& box, int part,
                             int part_lo, int part_hi, float omega = 0.f) {
     // the dynamic-LDS limit is an attribute of the function on a device: once per instantiation and
     // device (a process may hold contexts on several)
-    using G = FusedGeom<NT, RG>;
+    using G = typename FusedShape<NT, RG, T>::G;
+    static_assert(T == 2 || (T == 3 && !SOR), "two or three Jacobi sweeps per pass");
     // the kernel with streaming stores exists for the full-row Jacobi launches of grids 512 cells wide or wider
     constexpr bool STREAMING_VARIANT = !WIN && !SOR && NT >= 2 && RG >= 2;
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64] = {};  // contexts of different host threads share this table
     const size_t lds = G::lds_bytes;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, WIN, RG, KEEP, SOR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        const void* fn;
+        if constexpr (T == 3) fn = reinterpret_cast<const void*>(&k12_canon_t<NT, WIN, RG, 3, KEEP, false>);
+        else fn = reinterpret_cast<const void*>(&k12_canon2<NT, WIN, RG, KEEP, SOR>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);  // (setting it twice is harmless)
     }
     constexpr int TY = G::TY;
     FusedRange r = rg;
@@ -243,7 +261,7 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     const int seg1 = r.hole_lo - r.zout_lo, seg2 = r.zout_hi - r.hole_hi;
     const int depth = std::max(seg1, seg2);
     if (depth <= 0) return hipSuccess;
-    int zchunk = std::min(pick_zchunk(by, depth, cu_count()), depth);
+    int zchunk = std::min(pick_zchunk(by, depth, cu_count(), T), depth);
     // Sparse scene without a box (Z slab: the ghost planes are not covered by the activity map): most
     // workgroups leave at once and the few that work should be short, so that they run side by side.
     if (!box.valid && box.fraction >= 0.f &&
@@ -277,7 +295,7 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
         return e == nullptr ? 1 : atoi(e);
     }();
     if (xcd_ranges && by * nz >= 16) {
-        const XcdPlan plan = xcd_plan(by, r.nz_lo, nz, zchunk, seg1, seg2, cu_count());
+        const XcdPlan plan = xcd_plan(by, r.nz_lo, nz, zchunk, seg1, seg2, cu_count(), T);
         if (plan.on || xcd_ranges == 2) {
             int longest = 0;
             for (int x = 0; x < 8; x++) longest = std::max(longest, plan.start[x + 1] - plan.start[x]);
@@ -293,25 +311,42 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     if constexpr (STREAMING_VARIANT) {
         if (streaming) {
             FusedLaunchArgs a{grid, lds, s, mask, rhs, pin, pout, pmid, bricks, bk, g, p_oob, zchunk, r, omega};
-            return k12_launch_streaming<NT, RG, KEEP>(a);
+            if constexpr (T == 3) return k12_launch_streaming3<NT, RG, KEEP>(a);
+            else return k12_launch_streaming<NT, RG, KEEP>(a);
         }
     }
     (void)streaming;
-    hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP, SOR>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout,
-                       pmid, bricks, bk, g, p_oob, zchunk, r, omega);
+    if constexpr (T == 3)
+        hipLaunchKernelGGL((k12_canon_t<NT, WIN, RG, 3, KEEP, false>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin,
+                           pout, pmid, bricks, bk, g, p_oob, zchunk, r);
+    else
+        hipLaunchKernelGGL((k12_canon2<NT, WIN, RG, KEEP, SOR>), grid, dim3(G::THREADS), lds, s, mask, rhs, pin, pout,
+                           pmid, bricks, bk, g, p_oob, zchunk, r, omega);
     return hipSuccess;
 }
 
 // with / without the store of the odd iterate (the last pair of a loop keeps it)
-template <int NT, bool WIN, int RG>
+template <int NT, bool WIN, int RG, int T = 2>
 static hipError_t launch_nt(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                             float* pout, float* pmid, const uint8_t* bricks, const GridK& g, float p_oob,
                             const FusedRange& rg, const ActiveBox& box, int part, int part_lo, int part_hi) {
     if (pmid)
-        return launch_keep<NT, WIN, RG, true>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
-                                              part_lo, part_hi);
-    return launch_keep<NT, WIN, RG, false>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
-                                           part_lo, part_hi);
+        return launch_keep<NT, WIN, RG, true, false, T>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box,
+                                                        part, part_lo, part_hi);
+    return launch_keep<NT, WIN, RG, false, false, T>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part,
+                                                     part_lo, part_hi);
+}
+
+// is a launch shaped to `box` small enough that 16 thin wavefronts on many CUs beat 8 fat ones on few?
+// (512^3 dam break, x-window launches: 33.7 us per two-sweep launch with RG = 1, 37.2 with RG = 3).  Estimates
+// the workgroups of the fat shape (ty output rows each); below two per CU: thin.
+static inline bool small_box_launch(const GridK& g, const FusedRange& rg, const ActiveBox& box, int ty) {
+    if (!box.valid) return false;
+    const int rows = std::max(0, std::min(box.y_hi, g.H) - box.y_lo);
+    const int planes = (rg.zout_lo == 0 && rg.zout_hi == g.Dl) ? std::max(0, box.z_hi - box.z_lo)
+                                                               : rg.zout_hi - rg.zout_lo;
+    const int tiles = (rows + ty - 1) / std::max(ty, 1), chunks = (planes + 15) / 16;
+    return tiles * chunks < 2 * cu_count();
 }
 
 // the instantiation for the configured rows per wavefront

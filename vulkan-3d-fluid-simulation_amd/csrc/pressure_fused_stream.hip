@@ -9,15 +9,15 @@ namespace fluid {
 template <int NT, int RG, bool KEEP>
 hipError_t k12_launch_streaming(const FusedLaunchArgs& a) {
     using G = FusedGeom<NT, RG>;
-    static bool attr_set[64] = {};  // the dynamic-LDS limit: once per instantiation and device
+    static std::atomic<bool> attr_set[64] = {};  // the dynamic-LDS limit: once per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         const hipError_t e =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k12_canon2<NT, false, RG, KEEP, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k12_canon2<NT, false, RG, KEEP, false, true>), a.grid, dim3(G::THREADS), a.lds, a.stream,
                        a.mask, a.rhs, a.pin, a.pout, a.pmid, a.bricks, a.bk, a.g, a.p_oob, a.zchunk, a.r, a.omega);

@@ -141,7 +141,7 @@ struct EngineBackend : Backend {
     int loop_advance(uint32_t k, uint32_t sweeps, bool keep, int part, int32_t lo, int32_t hi,
                      int* written) override {
         if (fast) {
-            if (part != 0) return chk(fluid_pressure_loop_advance_part(c, keep, part, lo, hi, written));
+            if (part != 0) return chk(fluid_pressure_loop_advance_part_n(c, sweeps, keep, part, lo, hi, written));
             return chk(fluid_pressure_loop_advance(c, sweeps, keep, written));
         }
         *written = (int)((k + 1) % 2);
@@ -573,16 +573,41 @@ int reduce_max(fluid_slab* s, uint32_t* v, uint32_t n) {
 uint32_t effective_halo(fluid_slab* s, uint32_t max_sweeps, uint32_t max_halo) {
     // every rank must come to the same depth: limited by the thinnest slab of the partition
     uint32_t h = std::min(std::min(s->halo_depth, max_halo), s->thinnest);
-    if (max_sweeps >= 2 && h >= 2) h -= h % 2;
+    if (max_sweeps == 2 && h >= 2) h -= h % 2;  // pairs only: an odd plane would be exchanged for nothing
     return std::max<uint32_t>(h, 1);
+}
+
+// Sweeps of the next launch of a loop with `left` sweeps to go, at most `most` per launch: as many threes as
+// possible, no single sweep at the end unless the loop has only one (4 = 2 + 2).  (engine.hip has the same.)
+uint32_t next_launch_sweeps(uint32_t left, uint32_t most) {
+    if (left <= 1 || most <= 1) return std::min<uint32_t>(left, 1);
+    if (most == 2 || left == 2 || left == 4) return 2;
+    return 3;
+}
+// The next launch of a loop with `left` sweeps to go and `valid` ghost planes of the newest iterate: the sweeps
+// it applies and whether the slabs exchange h planes first.  Planes left over by the launches of three are used
+// up by a launch of two (h = 8: 3 + 3 + 2 sweeps between two exchanges).  A function of the loop's position
+// only: every rank comes to the same schedule.
+struct NextLaunch {
+    uint32_t sweeps;
+    bool exchange;
+};
+NextLaunch plan_launch(uint32_t left, int32_t valid, uint32_t most, uint32_t h) {
+    const uint32_t want = next_launch_sweeps(left, most);
+    if ((int32_t)want <= valid) return {want, false};
+    if (valid >= 2) {
+        const uint32_t alt = next_launch_sweeps(left, std::min<uint32_t>(most, (uint32_t)valid));
+        if (alt >= 2 && left - alt != 1) return {alt, false};
+    }
+    return {next_launch_sweeps(left, std::min(most, h)), true};
 }
 
 // FlowLoopPushConstantSection (fluid_flow_sections.h:300-313): dispatch k maps iterate k to
 // iterate k+1; after N dispatches PRESSURES_1 holds the last even iterate, PRESSURES_2 the last odd one.
 // Every sweep consumes one valid ghost plane per side of the newest iterate; when fewer are left than the
-// next launch needs (2 for a two-sweeps-per-pass launch) the slabs exchange h boundary planes — h sweeps
-// then run without communication, the engine recomputing the shrinking ghost region: the same bytes on
-// the wire as a plane per sweep in h times fewer messages.
+// next launch needs (2 or 3 for a launch of that many sweeps per pass) the slabs exchange h boundary planes —
+// h sweeps then run without communication, the engine recomputing the shrinking ghost region: the same bytes
+// on the wire as a plane per sweep in h times fewer messages.
 // Overlap (h >= 4, slabs thicker than 2h): the pass before an exchange is split — the h planes per face
 // that will be sent first, the exchange starts on the communication stream, the planes in between follow —
 // and so is the pass after it: the planes that depend on owned planes only while the exchange is in
@@ -599,27 +624,31 @@ int solve(fluid_slab* s, uint32_t n) {
     BE(loop_halo_exchanged(h, true));
     int32_t valid = (int32_t)h;  // valid ghost planes of the newest iterate
     int cur = 0;                 // buffer holding it
-    const bool pair = max_sweeps >= 2 && h >= 2;
-    const bool split = s->overlap != FLUID_SLAB_OVERLAP_NONE && pair && h >= 4 && s->thinnest > 2 * h &&
+    const uint32_t most = (max_sweeps >= 2 && h >= 2) ? std::min(max_sweeps, h) : 1;
+    const bool split = s->overlap != FLUID_SLAB_OVERLAP_NONE && most >= 2 && h >= 4 && s->thinnest > 2 * h &&
                        s->has_peers() && s->tr;
     const int32_t dl = (int32_t)s->dl, hh = (int32_t)h;
-    // interior of the pass before an exchange / of the pass after it (local output planes)
+    // interior of the pass before an exchange (local output planes)
     const int32_t before_lo = s->lo >= 0 ? hh : -kBig, before_hi = s->hi >= 0 ? dl - hh : kBig;
-    const int32_t after_lo = s->lo >= 0 ? 2 : -kBig, after_hi = s->hi >= 0 ? dl - 2 : kBig;
     bool in_flight = false;  // exchange started: finish before launching anything that reads ghost planes
     uint32_t k = 0;
     while (k < n) {
-        const uint32_t sweeps = (pair && n - k >= 2) ? 2 : 1;
-        const bool keep = sweeps == 2 && n - k == 2;
-        if (!in_flight && valid < (int32_t)sweeps) {
+        // (with an exchange in flight `valid` already counts the planes it brings)
+        const NextLaunch now = plan_launch(n - k, valid, most, h);
+        const uint32_t sweeps = now.sweeps;
+        const bool keep = sweeps >= 2 && n - k == sweeps;
+        if (now.exchange) {
             TRY(exchange_loop(s, cur, h));
             BE(loop_halo_exchanged(h, false));
             valid = hh;
         }
         const uint32_t left = n - k - sweeps;
-        const uint32_t next_sweeps = (pair && left >= 2) ? 2 : std::min<uint32_t>(left, 1);
-        int32_t valid_after = sweeps == 2 ? valid - 2 : 0;
-        if (in_flight && s->overlap == FLUID_SLAB_OVERLAP_BEFORE) {
+        int32_t valid_after = sweeps >= 2 ? valid - (int32_t)sweeps : 0;
+        const NextLaunch next = left ? plan_launch(left, valid_after, most, h) : NextLaunch{0, false};
+        // interior of the pass after an exchange: the planes whose inputs are owned planes only
+        const int32_t sw = (int32_t)sweeps;
+        const int32_t after_lo = s->lo >= 0 ? sw : -kBig, after_hi = s->hi >= 0 ? dl - sw : kBig;
+        if (in_flight && (s->overlap == FLUID_SLAB_OVERLAP_BEFORE || sweeps < 2)) {
             // half the overlap: only the pass before the exchange was split; wait, then a whole pass
             TRY(exchange_finish(s));
             in_flight = false;
@@ -627,18 +656,18 @@ int solve(fluid_slab* s, uint32_t n) {
         } else if (in_flight) {
             // first pass after the exchange started (valid == h: reported when it started)
             int w = 0;
-            BE(loop_advance(k, 2, keep, FLUID_LOOP_PART_INTERIOR, after_lo, after_hi, &w));
+            BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_INTERIOR, after_lo, after_hi, &w));
             TRY(exchange_finish(s));
             in_flight = false;
-            BE(loop_advance(k, 2, keep, FLUID_LOOP_PART_EDGES, after_lo, after_hi, &cur));
-        } else if (split && sweeps == 2 && next_sweeps == 2 && valid_after < 2) {
+            BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_EDGES, after_lo, after_hi, &cur));
+        } else if (split && sweeps >= 2 && next.exchange && next.sweeps >= 2) {
             int dst = 0;
-            BE(loop_advance(k, 2, keep, FLUID_LOOP_PART_EDGES, before_lo, before_hi, &dst));
+            BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_EDGES, before_lo, before_hi, &dst));
             const std::vector<Xfer>* plan = nullptr;
             TRY(get_plan(s, PLAN_LOOP, dst, h, &plan));
             TRY(exchange_start(s, *plan));
             in_flight = true;
-            BE(loop_advance(k, 2, keep, FLUID_LOOP_PART_INTERIOR, before_lo, before_hi, &cur));
+            BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_INTERIOR, before_lo, before_hi, &cur));
             BE(loop_halo_exchanged(h, false));  // started; the next pass orders itself behind it
             valid_after = hh;
         } else {
@@ -647,7 +676,7 @@ int solve(fluid_slab* s, uint32_t n) {
         valid = valid_after;
         k += sweeps;
     }
-    if (in_flight) TRY(exchange_finish(s));  // cannot happen: a split needs a following pair
+    if (in_flight) TRY(exchange_finish(s));  // cannot happen: a split needs a following fused pass
     BE(loop_end());
     return FLUID_OK;
 }

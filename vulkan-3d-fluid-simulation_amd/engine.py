@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "fluid_reset_timing", "fluid_image_plane_ptr", "fluid_notify_image_written",
     "fluid_notify_ghost_planes_written", "fluid_get_stat", "fluid_pressure_residual",
     "fluid_pressure_loop_begin", "fluid_pressure_loop_max_sweeps", "fluid_pressure_loop_advance",
-    "fluid_pressure_loop_advance_part", "fluid_pressure_loop_edge_stream",
+    "fluid_pressure_loop_advance_part", "fluid_pressure_loop_advance_part_n", "fluid_pressure_loop_edge_stream",
     "fluid_pressure_loop_halo_exchanged", "fluid_pressure_loop_end", "fluid_pressure_loop_plane_ptr",
     "fluid_slab_status", "fluid_particles_migrate_list", "fluid_particles_collect",
     "fluid_particles_adopt_received", "fluid_pressure_loop_available",
@@ -174,6 +174,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "fluid_pressure_loop_advance": (C.c_int, [vp, u32, C.c_int, C.POINTER(C.c_int)]),
         "fluid_pressure_loop_advance_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                                        C.POINTER(C.c_int)]),
+        "fluid_pressure_loop_advance_part_n": (C.c_int, [vp, u32, C.c_int, C.c_int, C.c_int32, C.c_int32,
+                                                         C.POINTER(C.c_int)]),
         "fluid_pressure_loop_edge_stream": (C.c_int, [vp, C.POINTER(vp)]),
         "fluid_pressure_loop_halo_exchanged": (C.c_int, [vp, u32, u32]),
         "fluid_pressure_loop_end": (C.c_int, [vp]),
@@ -538,13 +540,13 @@ class FluidEngine:
     LOOP_PART_EDGES, LOOP_PART_INTERIOR = 1, 2
 
     def pressure_loop_advance_part(self, keep_intermediate: bool, part: int, interior_begin: int,
-                                   interior_end: int) -> int:
-        """One of the two launches of a split two-sweep pass (include/fluid_engine.h)."""
+                                   interior_end: int, sweeps: int = 2) -> int:
+        """One of the two launches of a split pass of two or three sweeps (include/fluid_engine.h)."""
         written = C.c_int(-1)
         lo = max(int(interior_begin), -2 ** 31)
         hi = min(int(interior_end), 2 ** 31 - 1)
-        self._check(self._lib.fluid_pressure_loop_advance_part(
-            self._h, 1 if keep_intermediate else 0, part, lo, hi, C.byref(written)))
+        self._check(self._lib.fluid_pressure_loop_advance_part_n(
+            self._h, sweeps, 1 if keep_intermediate else 0, part, lo, hi, C.byref(written)))
         return int(written.value)
 
     def pressure_loop_edge_stream(self) -> int:
