@@ -18,11 +18,35 @@
 //   arithmetic in the shader's order.
 // 13 B/cell of HBM traffic buy T sweeps.  A launch consumes T ghost planes of iterate j (T-1 of mask / b_i)
 // per side (FusedRange).
+//
+// What it took to hold three iterates of three rows per wavefront in 256 registers without scratch, and to keep
+// the wavefronts' critical path short (measured with the stamps of `make trace`, tools/fused_trace3.py):
+//   * LDS rows are addressed as one of three address registers plus a 16-bit immediate (FusedGeomT::SEGF);
+//     left alone, hipcc kept one address register per row beyond 64 KB and spilled them;
+//   * global memory goes through buffer resources: a wave-uniform base (plane, row: SGPRs) plus ONE per-lane
+//     offset register for every access of the wavefront; stores are issued unconditionally, lanes that must
+//     not store carry an out-of-range offset (the hardware drops them) — with a branch around a store the
+//     compiler's wait for the step's loads also waited for the stores (vmcnt counts in issue order and a
+//     conditionally issued operation cannot be counted);
+//   * the reciprocals of the quotient come from v_rcp_f32 instead of an LDS table (div_pairs_rcp): nine
+//     dependent LDS round trips per plane step were the largest item of the step;
+//   * fix-ups of loaded values are selects, not wave-uniform branches with a wait each.
 #pragma once
 
 #include "kernels_pressure_fused.h"
 
 namespace fluid {
+
+// dev build only (make trace): cycles per phase of a plane step, as in kernels_pressure_fused.h
+#ifdef FLUID_FUSED_TRACE
+constexpr int FUSED3_TRACE_PHASES = 7;
+__device__ unsigned long long g_fused_trace3[64 * 16 * (FUSED3_TRACE_PHASES + 1)];
+#define FT3_ARG , FusedTrace& ftr
+#define FT3_PASS , ftr
+#else
+#define FT3_ARG
+#define FT3_PASS
+#endif
 
 template <int NT, int RG, int T>
 struct FusedGeomT {
@@ -35,16 +59,19 @@ struct FusedGeomT {
     static_assert(GROUPS >= 2, "a wavefront is the lower or the upper edge of its workgroup, not both");
     static_assert(TY >= 1, "no output rows");
     static constexpr int ROWS = 2 /*buffers*/ * T /*iterates*/ * R + 1 /*slack row in front*/;
-    static constexpr size_t lds_bytes = (size_t)ROWS * RW * sizeof(float) + 128 /* DivEntry table */;
+    static constexpr size_t lds_bytes = (size_t)(ROWS + 1 /*slack row behind*/) * RW * sizeof(float);
     // LDS addressing.  A ds instruction adds a 16-bit immediate to its address register, the rows span up to
     // 150 KB, and left alone hipcc keeps one address register per far row (dozens, spilled to scratch).  So:
     // three address registers per lane, SEGF floats apart, and every row access is one of them plus an immediate.
     static constexpr int SEGF = 15360;  // 61 440 bytes
-    static_assert((ROWS * RW + SEGF - 1) / SEGF <= 3, "three segments cover the rows");
+    static_assert(((ROWS + 1) * RW + SEGF - 1) / SEGF <= 3, "three segments cover the rows");
     // float offset of row (rr0 + dr), dr = -1 .. RG, of array `arr` in buffer `buf`, relative to row rr0 of the
     // slack row's position
     static constexpr int row_off(int buf, int arr, int dr) { return ((buf * T + arr) * R + dr + 1) * RW; }
 };
+
+// The planes a z chunk of a launch touches, for the buffer resources: [zb - T, ze + T]
+constexpr uint32_t FUSED3_OOB = 0x80000000u;  // a per-lane offset beyond every resource: the access is dropped
 
 // State of one row of a wavefront.  Every ring rotates with period 4 (the z loop is unrolled by 4: ring
 // indices are compile-time constants); in plane step zc with phase I:
@@ -58,36 +85,32 @@ struct FusedRowT {
     float4 it[T][4], b[4];
     uint32_t m[4];
     float padv[4];
-    int roff;                 // element offset of the row within a plane (wave-uniform: lives in an SGPR)
-    bool row_in, pad_in;      // those cells exist
-    bool is_out_row;          // ... and the row is one the workgroup writes
+    uint32_t roff4;   // byte offset of the row within a plane (wave-uniform: an SGPR)
+    bool yin;         // the row exists (wave-uniform)
+    bool out_row;     // ... and is one the workgroup writes (wave-uniform)
 };
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 template <int NT, int RG, int T>
 struct FusedCtxT {
     using G = FusedGeomT<NT, RG, T>;
-    const uint8_t* mask;
-    const float* rhs;
-    const float* pin;
-    float* pout;
-    float* pmid;
-    FLUID_LDS float* lds;
-    const FLUID_LDS char* divtab;
+    __amdgpu_buffer_rsrc_t rj, rb, rm, ro, rk;  // iterate j, b_i, mask, output, kept iterate: base = plane zbase
     uint32_t lb[3], le[3], lp[3];  // LDS byte addresses (G::SEGF apart) of this lane's cells / its seam cell /
                                    // its pad cell (windowed launches) in row rr0 of the slack row's position
-    int64_t plane;
+    uint32_t plane_b;              // bytes per plane of a float array
+    int zbase;                     // plane at offset 0 of the buffer resources
     int zb, ze;
     int jlo, jhi, mlo, mhi;  // planes that hold cells of the grid (FusedRange)
-    int lane, rr0, x0, xe;
-    unsigned loff, loff_pad;  // byte offset of this lane's cells / of its pad column within a row: every global
-                              // access is a wave-uniform base (plane, row) plus one of these
-    int roff_h;               // the row just outside the workgroup (edge wavefronts)
+    int lane, rr0;
+    uint32_t loff, loff_pad;  // byte offset of this lane's cells / of its pad column within a row: every global
+                              // access is a wave-uniform offset (plane, row) plus one of these
+    uint32_t roff4_h;         // the row just outside the workgroup (edge wavefronts)
+    bool xin, col_in;         // per lane: its cells / its pad column lie inside the grid
     bool pad_writer;
-    int pad_x;
     float p_oob;
-    bool halo_in;
+    bool yin_h;             // wave-uniform: that outer row exists
     bool halo_lo, halo_hi;  // wave-uniform: this group holds row 0 / row R-1 of the workgroup
-    bool wave_clean;
 
     // row rr0 + dr of (buf, arr): this lane's cells / seam cell / pad cell.  All arguments are compile-time
     // constants where this is called, so the result is an address register plus an immediate.
@@ -106,26 +129,54 @@ struct FusedCtxT {
     }
     __device__ __forceinline__ bool j_ok(int lz) const { return lz >= jlo && lz < jhi; }
     __device__ __forceinline__ bool m_ok(int lz) const { return lz >= mlo && lz < mhi; }
-    __device__ __forceinline__ int64_t j_off(int lz) const { return j_ok(lz) ? (int64_t)lz * plane : (int64_t)0; }
-    __device__ __forceinline__ int64_t m_off(int lz) const { return m_ok(lz) ? (int64_t)lz * plane : (int64_t)0; }
+    // wave-uniform byte offset of plane lz, redirected to the resources' first plane when lz is outside the
+    // grid: loads are always issued, from a valid address, and the value is replaced later (fix_*)
+    __device__ __forceinline__ uint32_t j_soff(int lz) const { return j_ok(lz) ? (uint32_t)(lz - zbase) * plane_b : 0u; }
+    __device__ __forceinline__ uint32_t m_soff(int lz) const { return m_ok(lz) ? (uint32_t)(lz - zbase) * plane_b : 0u; }
+    __device__ __forceinline__ float4 ld4(__amdgpu_buffer_rsrc_t r, uint32_t soff) const {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, loff, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    // (selects, no branch: the values were loaded a step ago, and a wave-uniform shortcut here cost a branch
+    // per row with its own wait for the loads)
     __device__ __forceinline__ float4 fix_j(float4 v, bool ok, int lz) const {
-        if (wave_clean && j_ok(lz)) return v;
-        const float4 pa4 = make_float4(p_oob, p_oob, p_oob, p_oob);
-        return (ok && j_ok(lz)) ? v : pa4;
+        const bool keep = ok && j_ok(lz);
+        return make_float4(keep ? v.x : p_oob, keep ? v.y : p_oob, keep ? v.z : p_oob, keep ? v.w : p_oob);
     }
     __device__ __forceinline__ float fix_pad(float v, bool pad_in, int lz) const {
         return (pad_in && j_ok(lz)) ? v : p_oob;
     }
     __device__ __forceinline__ uint32_t fix_m(uint32_t m, bool row_in, int lz) const {
-        if (wave_clean && m_ok(lz)) return m;
         return (m_ok(lz) && row_in) ? m : MASK_DRY4;
     }
 };
 
+// The (aii, reciprocal) pairs of a lane's four cells without the LDS table of kernels_pressure_fused.h: aii by
+// v_cvt_f32_ubyte, the reciprocal by v_rcp_f32.  On gfx950 v_rcp_f32 returns RN(1 / a) for a = 1, 2, 4, 5 and the
+// truncated value (one ulp below) for a = 3 and 6 (tools/micro/rcp_small_int.hip; the GPU suite checks it);
+// tests/divide_small_int_check.c proves the quotient chain of div_small_int exact for all |n| >= 2^-125 with
+// either value.  A table look-up per row and stage was a dependent LDS round trip on the wavefront's critical
+// path: nine per plane step.
+__device__ __forceinline__ DivPairs div_pairs_rcp(uint32_t m) {
+    DivPairs d;
+    const float a0 = (float)(m & 0xFFu), a1 = (float)((m >> 8) & 0xFFu), a2 = (float)((m >> 16) & 0xFFu),
+                a3 = (float)(m >> 24);
+    d.c[0] = make_float2(a0, __builtin_amdgcn_rcpf(a0));
+    d.c[1] = make_float2(a1, __builtin_amdgcn_rcpf(a1));
+    d.c[2] = make_float2(a2, __builtin_amdgcn_rcpf(a2));
+    d.c[3] = make_float2(a3, __builtin_amdgcn_rcpf(a3));
+    return d;
+}
+
+#ifndef FT3_LOAD_AFTER
+#define FT3_LOAD_AFTER 1
+#endif
+
 // One plane step (see kernels_pressure_fused.h: fused_step for why the order is what it is).
 template <int NT, int RG, int T, int I, bool WIN, bool KEEP, bool NTS>
 __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, FusedRowT<T> (&row)[RG], float4 (&h)[2],
-                                             int zc) {
+                                             int zc FT3_ARG) {
+    FT_BEGIN();
     using G = FusedGeomT<NT, RG, T>;
     constexpr int buf = I & 1;
     constexpr int S0 = I & 3, S1 = (I + 1) & 3, S2 = (I + 2) & 3, S3 = (I + 3) & 3;
@@ -137,8 +188,10 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
     float4 ext_lo[T], ext_hi[T];
     float edge[T][RG];
     auto lds_reads = [&](int r) {
-        if (!c.halo_lo) ext_lo[r] = lds_ld4(c.cells(buf, r, -1));
-        if (!c.halo_hi) ext_hi[r] = lds_ld4(c.cells(buf, r, RG));
+        // (also by the groups at the workgroup's edges, whose outer row is another array's, or a slack row:
+        // they do not use what they read, and a branch around the read costs more than the read)
+        ext_lo[r] = lds_ld4(c.cells(buf, r, -1));
+        ext_hi[r] = lds_ld4(c.cells(buf, r, RG));
 #pragma unroll
         for (int i = 0; i < RG; i++) edge[r][i] = X_EDGE_FROM_LDS ? *c.seam(buf, r, i) : c.p_oob;
     };
@@ -150,20 +203,20 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
     bool wet[RG];
 #pragma unroll
     for (int i = 0; i < RG; i++) {
-        row[i].it[0][S2] = c.fix_j(row[i].it[0][S2], row[i].row_in, zc + 1);
-        row[i].m[S2] = c.fix_m(row[i].m[S2], row[i].row_in, zc);
-        wet[i] = zo_in && row[i].is_out_row && mask_any_water(row[i].m[(I + 2 - (T - 1)) & 3]);
+        const bool row_in = c.xin && row[i].yin;
+        row[i].it[0][S2] = c.fix_j(row[i].it[0][S2], row_in, zc + 1);
+        row[i].m[S2] = c.fix_m(row[i].m[S2], row_in, zc);
+        wet[i] = zo_in && row[i].out_row && c.xin && mask_any_water(row[i].m[(I + 2 - (T - 1)) & 3]);
     }
-    if (is_halo) {
-        const float4 hc = c.fix_j(h[I & 1], c.halo_in, zc);
-        if (c.halo_lo) ext_lo[0] = hc; else ext_hi[0] = hc;
+    {
+        const float4 hc = c.fix_j(h[I & 1], c.xin && c.yin_h, zc);
+        if (c.halo_lo) ext_lo[0] = hc;
+        if (c.halo_hi) ext_hi[0] = hc;
     }
 
+    FT(0);  // LDS reads issued, wait for the previous step's loads, fix-ups
     // ---- the stages
-    const int64_t oo = (int64_t)(zo_in ? zo : c.zb) * c.plane;
-#ifndef FT3_LOAD_AFTER
-#define FT3_LOAD_AFTER 0
-#endif
+    const uint32_t oo = (uint32_t)((zo_in ? zo : c.zb) - c.zbase) * c.plane_b;
     constexpr int LOAD_AFTER = (T >= 3 && RG >= 2) ? FT3_LOAD_AFTER : 0;  // the stage behind which the global loads are issued
 #pragma unroll
     for (int k = 0; k < T; k++) {
@@ -181,7 +234,7 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
 #pragma unroll
             for (int i = 0; i < RG; i++) {
                 if (c.rr0 + i < k || c.rr0 + i > G::R - 1 - k) continue;  // wave-uniform
-                const DivPairs d = div_pairs(row[i].m[MS], c.divtab);
+                const DivPairs d = div_pairs_rcp(row[i].m[MS]);
                 const float4 ce = row[i].it[k][S1];
                 const float4 ym = i > 0 ? row[i > 0 ? i - 1 : 0].it[k][S1] : ext_lo[k];
                 const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].it[k][S1] : ext_hi[k];
@@ -189,9 +242,6 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
                 const float right = from_lane_above(ce.x, edge[k][i], c.lane);
                 v[i] = canon_lane<false, (NT >= 2)>(row[i].b[MS], row[i].m[MS], ce, yp, row[i].it[k][S2], ym,
                                                     row[i].it[k][S0], left, right, d);
-#ifdef FT3_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
 #pragma unroll
@@ -199,29 +249,48 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
             if (k < T - 1) {
                 row[i].it[k + 1][S2] = v[i];
             } else {
-                // stores: every condition is in the lane predicate; a lane stores only if one of its four cells
-                // is water
-                if (wet[i]) st_f4<NTS>(c.pout + oo + row[i].roff, c.loff, v[i]);
+                // stores: issued by every wavefront in every step (an exact count for the waits on the loads
+                // around them); a lane stores only if one of its four cells is water, the others — and every
+                // lane of a step outside the chunk, of a halo row — carry an offset the hardware drops
+                const uint32_t vo = wet[i] ? c.loff : FUSED3_OOB;
+                const u32x4_t bits = {__float_as_uint(v[i].x), __float_as_uint(v[i].y), __float_as_uint(v[i].z),
+                                      __float_as_uint(v[i].w)};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, c.ro, vo, oo + row[i].roff4, NTS ? 2 : 0);
                 if (KEEP) {  // iterate j+T-1, kept only by the last launch of a loop
-                    if (wet[i]) st_f4<NTS>(c.pmid + oo + row[i].roff, c.loff, row[i].it[T - 1][S1]);
+                    const float4 km = row[i].it[T - 1][S1];
+                    const u32x4_t kb = {__float_as_uint(km.x), __float_as_uint(km.y), __float_as_uint(km.z),
+                                        __float_as_uint(km.w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(kb, c.rk, vo, oo + row[i].roff4, NTS ? 2 : 0);
                 }
             }
         }
+#ifdef FLUID_FUSED_TRACE
+        asm volatile("" ::"v"(v[0].x), "v"(v[RG - 1].w));  // the stage is done here
+        if (k == 0) FT(1);
+        if (k == 1) FT(2);
+        if (k == 2) FT(3);
+#endif
         if (k == LOAD_AFTER) {
             // ---- iterate j two planes ahead (raw; fixed up in the next step), b_i and mask (and the row outside
             // the workgroup) one plane ahead, into registers of planes that are dead from here on
-            const int64_t o2 = c.j_off(zc + 2);
-            const int64_t o1 = c.j_off(zc + 1), a1 = c.m_off(zc + 1);
+            const uint32_t o2 = c.j_soff(zc + 2), o1 = c.j_soff(zc + 1), a1 = c.m_soff(zc + 1);
 #pragma unroll
             for (int i = 0; i < RG; i++) {
-                row[i].it[0][S3] = ld_f4(c.pin + o2 + row[i].roff, c.loff);
+                row[i].it[0][S3] = c.ld4(c.rj, o2 + row[i].roff4);
                 if (WIN)
-                    row[i].padv[S3] = *reinterpret_cast<const float*>(
-                        reinterpret_cast<const char*>(c.pin + o2 + row[i].roff) + c.loff_pad);
-                row[i].b[S3] = ld_f4(c.rhs + a1 + row[i].roff, c.loff);
-                row[i].m[S3] = ld_u32(c.mask + a1 + row[i].roff, c.loff >> 2);
+                    row[i].padv[S3] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(c.rj, c.loff_pad, o2 + row[i].roff4, 0));
+                row[i].b[S3] = c.ld4(c.rb, a1 + row[i].roff4);
+                row[i].m[S3] = __builtin_amdgcn_raw_buffer_load_b32(c.rm, c.loff >> 2, (a1 + row[i].roff4) >> 2, 0);
             }
-            if (is_halo) h[(I + 1) & 1] = ld_f4(c.pin + o1 + c.roff_h, c.loff);
+            // (issued by every wavefront, so that the count of loads in flight is the same on every path; only the
+            // groups at the workgroup's edges fetch anything)
+            {
+                const u32x4_t hv = __builtin_amdgcn_raw_buffer_load_b128(c.rj, is_halo ? c.loff : FUSED3_OOB,
+                                                                         o1 + c.roff4_h, 0);
+                h[(I + 1) & 1] = make_float4(__uint_as_float(hv.x), __uint_as_float(hv.y), __uint_as_float(hv.z),
+                                             __uint_as_float(hv.w));
+            }
         }
     }
 
@@ -236,12 +305,15 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
                 if (WIN) {
                     // the columns next to the window hold non-water constants: the same value in every iterate
                     if (c.pad_writer)
-                        *c.padc(nbuf, r, i) = c.fix_pad(row[i].padv[(I + 2 - r) & 3], row[i].pad_in, zc + 1 - r);
+                        *c.padc(nbuf, r, i) =
+                            c.fix_pad(row[i].padv[(I + 2 - r) & 3], c.col_in && row[i].yin, zc + 1 - r);
                 }
             }
         }
     }
+    FT(4);  // publish
     __syncthreads();
+    FT(5);  // barrier
 }
 
 template <int NT, bool WIN, int RG, int T, bool KEEP, bool NTS = false>
@@ -254,13 +326,6 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     FusedCtxT<NT, RG, T> c;
-    c.mask = mask;
-    c.rhs = rhs;
-    c.pin = pin;
-    c.pout = pout;
-    c.pmid = pmid;
-    c.lds = (FLUID_LDS float*)lds;
-    c.plane = g.plane;
     c.jlo = rg.jlo;
     c.jhi = rg.jhi;
     c.mlo = rg.mlo;
@@ -270,7 +335,7 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = wave % NT;
     c.rr0 = (wave / NT) * RG;
-    c.x0 = tx * 256 + c.lane * 4;
+    const int x0 = tx * 256 + c.lane * 4;
     int tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
     if (rg.xcd_rows > 0) {
         const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
@@ -289,8 +354,9 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
     }
 
     if (c.zb >= 0 && c.ze <= g.Dl) {
-        // the whole group leaves if no brick it touches holds water (uniform: before any barrier); an output
-        // cell moves only if it is water, and then its brick is active
+        // the whole group leaves if no brick it writes into holds water (uniform: before any barrier): an output
+        // cell moves only if it is water, and then its brick is active; groups that write ghost planes always
+        // run (the activity map covers owned planes only)
         uint32_t any = 0;
         const int by0 = max(y0, 0) / BRICK_Y, by1 = min(y0 + TY - 1, g.H - 1) / BRICK_Y;
         const int bz0 = max(c.zb, 0) / BRICK_Z, bz1 = min(c.ze - 1, g.Dl - 1) / BRICK_Z;
@@ -300,62 +366,66 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
         if (any == 0) return;
     }
 
-    const int gx0 = (WIN ? rg.xwin0 : 0) + c.x0;  // global x of this lane's first cell
-    const bool xin = gx0 < g.W;
-    const unsigned xs = xin ? (unsigned)gx0 : 0u;
+    // buffer resources over the planes [zb - T, ze + T] of this chunk (the working buffers carry LOOP_GHOST >= T
+    // ghost planes per side whatever the context, so the planes exist; the launch code checks that the range
+    // stays below 2 GB)
+    c.zbase = c.zb - T;
+    c.plane_b = 4u * (uint32_t)g.plane;
+    {
+        const int64_t base = (int64_t)c.zbase * g.plane;
+        const uint32_t span = (uint32_t)(c.ze - c.zb + 2 * T + 1) * c.plane_b;
+        c.rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + base), 0, span, 0x00020000);
+        c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rhs + base), 0, span, 0x00020000);
+        c.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mask + base), 0, span >> 2, 0x00020000);
+        c.ro = __builtin_amdgcn_make_buffer_rsrc(pout + base, 0, span, 0x00020000);
+        c.rk = __builtin_amdgcn_make_buffer_rsrc((KEEP ? pmid : pout) + base, 0, span, 0x00020000);
+    }
+
+    const int gx0 = (WIN ? rg.xwin0 : 0) + x0;  // global x of this lane's first cell
+    c.xin = gx0 < g.W;
+    const unsigned xs = c.xin ? (unsigned)gx0 : 0u;
     c.halo_lo = c.rr0 == 0;
     c.halo_hi = c.rr0 + RG == R;
     FusedRowT<T> row[RG];
-    bool dirty = false;
     const int xl = rg.xwin0 - 1, xr = rg.xwin0 + NT * 256;  // the columns next to the window (WIN)
     const int gxp = c.lane < 32 ? xl : xr;
-    const bool col_in = (unsigned)gxp < (unsigned)g.W;
+    c.col_in = (unsigned)gxp < (unsigned)g.W;
     const int yrow0 = y0 - (T - 1);  // row 0 of the workgroup
 #pragma unroll
     for (int i = 0; i < RG; i++) {
         const int y = yrow0 + c.rr0 + i;
         const bool yin = (unsigned)y < (unsigned)g.H;
-        row[i].row_in = xin && yin;
-        row[i].is_out_row = c.rr0 + i >= T - 1 && c.rr0 + i <= R - T && row[i].row_in;
-        row[i].roff = __builtin_amdgcn_readfirstlane(g.W * (yin ? y : 0));
-        row[i].pad_in = col_in && yin;
-        dirty = dirty || !row[i].row_in;
+        row[i].yin = yin;
+        row[i].out_row = c.rr0 + i >= T - 1 && c.rr0 + i <= R - T && yin;
+        row[i].roff4 = (uint32_t)__builtin_amdgcn_readfirstlane(4 * g.W * (yin ? y : 0));
     }
     const int yh = c.halo_lo ? yrow0 - 1 : yrow0 + R;  // the row just outside the workgroup
     const bool is_halo = c.halo_lo || c.halo_hi;
-    c.halo_in = is_halo && xin && (unsigned)yh < (unsigned)g.H;
-    c.roff_h = __builtin_amdgcn_readfirstlane(g.W * (((unsigned)yh < (unsigned)g.H) ? yh : 0));
+    c.yin_h = is_halo && (unsigned)yh < (unsigned)g.H;
+    c.roff4_h = (uint32_t)__builtin_amdgcn_readfirstlane(4 * g.W * (((unsigned)yh < (unsigned)g.H) ? yh : 0));
     c.loff = 4u * xs;
-    c.loff_pad = 4u * (col_in ? (unsigned)gxp : 0u);
-    c.wave_clean = __builtin_amdgcn_ballot_w64(dirty || (is_halo && !c.halo_in)) == 0ull;
-    c.xe = c.lane == 0 ? c.x0 - 1 : c.x0 + 4;
+    c.loff_pad = 4u * (c.col_in ? (unsigned)gxp : 0u);
+    // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
+    const int xe = c.lane == 0 ? x0 - 1 : x0 + 4;
     c.pad_writer = (c.lane == 0 && tx == 0) || (c.lane == 63 && tx == NT - 1);
-    c.pad_x = c.lane == 0 ? -1 : NT * 256;
+    const int pad_x = c.lane == 0 ? -1 : NT * 256;
 
+    FLUID_LDS float* const ldsp = (FLUID_LDS float*)lds;
     {
         // the three address registers per kind; opaque to the compiler from here on, so that it keeps them
-        const uint32_t row0 = (uint32_t)(uintptr_t)c.lds + 4u * (uint32_t)(FUSED_PAD + c.rr0 * RW);
+        const uint32_t row0 = (uint32_t)(uintptr_t)ldsp + 4u * (uint32_t)(FUSED_PAD + c.rr0 * RW);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            c.lb[q] = row0 + 4u * (uint32_t)(c.x0 + q * G::SEGF);
-            c.le[q] = row0 + 4u * (uint32_t)(c.xe + q * G::SEGF);
-            c.lp[q] = row0 + 4u * (uint32_t)(c.pad_x + q * G::SEGF);
+            c.lb[q] = row0 + 4u * (uint32_t)(x0 + q * G::SEGF);
+            c.le[q] = row0 + 4u * (uint32_t)(xe + q * G::SEGF);
+            c.lp[q] = row0 + 4u * (uint32_t)(pad_x + q * G::SEGF);
             asm volatile("" : "+v"(c.lb[q]), "+v"(c.le[q]), "+v"(c.lp[q]));
         }
     }
-    {   // DivEntry table
-        FLUID_LDS float* tab = c.lds + G::ROWS * RW;
-        c.divtab = (const FLUID_LDS char*)tab;
-        if (threadIdx.x < DIV_TABLE_ENTRIES) {
-            const float a = (float)threadIdx.x;
-            tab[2 * threadIdx.x] = a;
-            tab[2 * threadIdx.x + 1] = threadIdx.x == 0 ? 0.0f : 1.0f / a;  // RN(1/a): IEEE division
-        }
-    }
     // pad cells of every LDS row: x = -1 and x = NT*256 read as p_oob (outside the grid)
-    for (int i = threadIdx.x; i < G::ROWS * 2 * FUSED_PAD; i += G::THREADS) {
+    for (int i = threadIdx.x; i < (G::ROWS + 1) * 2 * FUSED_PAD; i += G::THREADS) {
         const int side = i % (2 * FUSED_PAD), r = i / (2 * FUSED_PAD);
-        FLUID_LDS float* base = c.lds + r * RW;
+        FLUID_LDS float* base = ldsp + r * RW;
         base[side < FUSED_PAD ? side : RW - 2 * FUSED_PAD + side] = p_air;
     }
 
@@ -366,9 +436,10 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
 #pragma unroll
     for (int i = 0; i < RG; i++) {
         FusedRowT<T>& r = row[i];
-        r.it[0][0] = c.fix_j(ld_f4(pin + c.j_off(zc - 1) + r.roff, c.loff), r.row_in, zc - 1);
-        r.it[0][1] = c.fix_j(ld_f4(pin + c.j_off(zc) + r.roff, c.loff), r.row_in, zc);
-        r.it[0][2] = ld_f4(pin + c.j_off(zc + 1) + r.roff, c.loff);  // raw: fixed up by the first step
+        const bool row_in = c.xin && r.yin;
+        r.it[0][0] = c.fix_j(c.ld4(c.rj, c.j_soff(zc - 1) + r.roff4), row_in, zc - 1);
+        r.it[0][1] = c.fix_j(c.ld4(c.rj, c.j_soff(zc) + r.roff4), row_in, zc);
+        r.it[0][2] = c.ld4(c.rj, c.j_soff(zc + 1) + r.roff4);  // raw: fixed up by the first step
 #pragma unroll
         for (int q = 1; q < T; q++) {
             r.it[q][0] = pa4;  // planes below the first one the march forms: whatever is computed from them is
@@ -376,19 +447,18 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
         }
         r.b[0] = r.b[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         r.m[0] = r.m[1] = MASK_DRY4;
-        r.b[2] = ld_f4(rhs + c.m_off(zc) + r.roff, c.loff);
-        r.m[2] = ld_u32(mask + c.m_off(zc) + r.roff, c.loff >> 2);
+        r.b[2] = c.ld4(c.rb, c.m_soff(zc) + r.roff4);
+        r.m[2] = __builtin_amdgcn_raw_buffer_load_b32(c.rm, c.loff >> 2, (c.m_soff(zc) + r.roff4) >> 2, 0);
         if (WIN) {
             auto pad_at = [&](int lz) {
-                return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pin + c.j_off(lz) + r.roff) +
-                                                       c.loff_pad);
+                return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rj, c.loff_pad, c.j_soff(lz) + r.roff4, 0));
             };
             r.padv[0] = pad_at(zc - 1);
             r.padv[1] = pad_at(zc);
             r.padv[2] = pad_at(zc + 1);
         }
     }
-    h[0] = ld_f4(pin + c.j_off(zc) + c.roff_h, c.loff);
+    h[0] = c.ld4(c.rj, c.j_soff(zc) + c.roff4_h);
     __syncthreads();  // pad cells are in place (the rows below overwrite two of them in windowed launches)
     // what the first step expects behind its barrier: iterate j+r at plane zc-r
 #pragma unroll
@@ -400,22 +470,39 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
             if (WIN) {
                 // (the pad column of the planes below zc-1 is not on hand: plane zc-1's value stands in; it
                 // only feeds values of the warm-up planes, which are never stored)
-                if (c.pad_writer) *c.padc(0, q, i) = c.fix_pad(r.padv[q == 0 ? 1 : 0], r.pad_in, q == 0 ? zc : zc - 1);
+                if (c.pad_writer)
+                    *c.padc(0, q, i) = c.fix_pad(r.padv[q == 0 ? 1 : 0], c.col_in && r.yin, q == 0 ? zc : zc - 1);
             }
         }
     }
     __syncthreads();
 
     const int steps = c.ze - c.zb + 2 * (T - 1);
+#ifdef FLUID_FUSED_TRACE
+    FusedTrace ftr;
+    for (int i = 0; i < FUSED_TRACE_PHASES; i++) ftr.sum[i] = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < steps; k += 4, zc += 4) {
-        fused_step_t<NT, RG, T, 0, WIN, KEEP, NTS>(c, row, h, zc);
+        fused_step_t<NT, RG, T, 0, WIN, KEEP, NTS>(c, row, h, zc FT3_PASS);
         if (k + 1 >= steps) break;  // all wave-uniform: every wavefront takes the same barriers
-        fused_step_t<NT, RG, T, 1, WIN, KEEP, NTS>(c, row, h, zc + 1);
+        fused_step_t<NT, RG, T, 1, WIN, KEEP, NTS>(c, row, h, zc + 1 FT3_PASS);
         if (k + 2 >= steps) break;
-        fused_step_t<NT, RG, T, 2, WIN, KEEP, NTS>(c, row, h, zc + 2);
+        fused_step_t<NT, RG, T, 2, WIN, KEEP, NTS>(c, row, h, zc + 2 FT3_PASS);
         if (k + 3 >= steps) break;
-        fused_step_t<NT, RG, T, 3, WIN, KEEP, NTS>(c, row, h, zc + 3);
+        fused_step_t<NT, RG, T, 3, WIN, KEEP, NTS>(c, row, h, zc + 3 FT3_PASS);
     }
+#ifdef FLUID_FUSED_TRACE
+    {
+        const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (wg < 64 && c.lane == 0) {
+            unsigned long long* o = g_fused_trace3 + (wg * 16 + wave) * (FUSED3_TRACE_PHASES + 1);
+            for (int i = 0; i < FUSED_TRACE_PHASES; i++) o[i] = ftr.sum[i];
+            o[6] = __builtin_amdgcn_s_memtime() - t_begin;  // whole march
+            o[FUSED3_TRACE_PHASES] = (unsigned long long)steps;
+        }
+    }
+#endif
 }
 
 }  // namespace fluid

@@ -6,7 +6,9 @@ namespace fluid {
 
 // Grids up to 512 cells wide: NT <= 2 x tiles leave 8 (NT = 2) or 20 / 12 (NT = 1) output rows per workgroup.
 // At NT = 4 the workgroup's 6 rows would leave 2: those grids stay with two sweeps per pass.
-bool k12_canon3_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 512 && g.Dl >= 3; }
+// The kernel addresses a z chunk's planes through buffer resources with 32-bit offsets below 2 GB (140 planes
+// of W x H floats at most): H <= 4096.
+bool k12_canon3_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 512 && g.H <= 4096 && g.Dl >= 3; }
 
 template <int NT, int RG, bool KEEP>
 hipError_t k12_launch_streaming3(const FusedLaunchArgs& a) {
@@ -81,3 +83,10 @@ hipError_t k12_launch_canon3(hipStream_t s, const uint8_t* mask, const float* rh
 }
 
 }  // namespace fluid
+
+#ifdef FLUID_FUSED_TRACE
+// dev build: copy the phase sums of the last three-sweep launch out (tools/fused_trace3.py)
+extern "C" int fluid_dev_fused_trace3(unsigned long long* out, int words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fluid::g_fused_trace3), sizeof(unsigned long long) * words);
+}
+#endif
