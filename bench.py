@@ -69,8 +69,8 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-FUSED_KERNEL_SOURCES = ["kernels_pressure_fused.h", "pressure_fused_launch.h", "pressure_fused.hip",
-                        "pressure_fused_stream.hip", "pressure_common.h"]
+FUSED_KERNEL_SOURCES = ["kernels_pressure_fused.h", "kernels_pressure_fused3.h", "pressure_fused_launch.h",
+                        "pressure_fused.hip", "pressure_fused3.hip", "pressure_fused_stream.hip", "pressure_common.h"]
 
 
 def kernel_sources_sha16():
@@ -636,8 +636,10 @@ def slab_rank_main(args, ranks=None):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": None,
-                         "kernel": "k12_canon2 (per GPU, on its slab; two sweeps per launch)"
-                                   if w % 4 == 0 and w <= 1024 else "k12_zmarch / k12_plain",
+                         "kernel": ("k12_canon_t (per GPU, on its slab; launches of 3 + 3 + 2 sweeps between two "
+                                    "exchanges of 8 planes)" if w % 4 == 0 and w <= 512 else
+                                    "k12_canon2 (per GPU, on its slab; two sweeps per launch)"
+                                    if w % 4 == 0 and w <= 1024 else "k12_zmarch / k12_plain"),
                          "kernel_ms_per_sweep": kernel_ms,
                          "note": "achieved = 13 B x local cells / kernel time per sweep (HIP events "
                                  "on the engine's stream, MAX over ranks); ghost-plane recompute "
@@ -693,6 +695,7 @@ def main(argv=None):
     eng.set_option(E.OPT_PRESSURE_KERNEL, args.pressure_kernel)
     if args.no_fuse:
         eng.set_option(E.OPT_JACOBI_FUSE, 1)
+    sweeps_per_launch = eng.pressure_loop_max_sweeps()   # 3 up to 512 cells wide, 2 above, 1 with --no-fuse
     shape = (d, h, w)
     eng.upload_image(E.CELL_TYPES, scenes.full_fluid_types(shape))
     eng.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence(shape, scenes.SEED_JACOBI + rank))
@@ -725,17 +728,19 @@ def main(argv=None):
     cells = w * h * d
     sweeps = args.steps * args.iters
     assert dispatches == sweeps, (dispatches, sweeps)  # loop sections count their sweeps
-    # The loop section runs two sweeps per kernel launch (temporal blocking) unless --no-fuse: one
-    # launch then carries 2 x 13 B/cell of algorithmic traffic.  HIP events bracket the whole loop
-    # section (import / export passes included), so the per-launch figure is conservative.  The loop's mask /
-    # b_i pass (k12_prepare) runs only when CELL_TYPES / DIVERGENCES change: once per step in a simulation
-    # (0.45 ms at 512^3, 1 % of a 200-iteration loop; inside full_step and full_step_dense), once in all here.
-    fused = (not args.no_fuse) and w % 4 == 0 and w <= 1024
-    sweeps_per_launch = 2 if fused else 1
+    # The loop section runs three (grids up to 512 cells wide) or two sweeps per kernel launch (temporal
+    # blocking) unless --no-fuse: one launch then carries 3 (2) x 13 B/cell of algorithmic traffic.  A loop of
+    # 200 is 66 launches of three and one of two; HIP events bracket the whole loop section (import / export
+    # passes included) and the time is divided evenly over the sweeps, so the per-launch figure of the
+    # dominant kernel is conservative.  The loop's mask / b_i pass (k12_prepare) runs only when CELL_TYPES /
+    # DIVERGENCES change: once per step in a simulation (0.45 ms at 512^3, 1 % of a 200-iteration loop; inside
+    # full_step and full_step_dense), once in all here.
+    fused = sweeps_per_launch >= 2
     launch_ms = loop_ms / sweeps * sweeps_per_launch
     kernel_ms = loop_ms / sweeps  # per sweep
     achieved = JACOBI_BYTES_PER_CELL * cells * sweeps_per_launch / (launch_ms * 1e-3) / 1e9
-    kernel_name = ("k12_canon2" if fused else "k12_canon") if w % 4 == 0 else "k12_plain"
+    kernel_name = ({3: "k12_canon_t", 2: "k12_canon2"}.get(sweeps_per_launch, "k12_canon")
+                   if w % 4 == 0 else "k12_plain")
     traffic, traffic_source = recorded_traffic(kernel_name, size)
     out = {
         "metric": "pressure_jacobi_iterations_per_sec",
@@ -763,8 +768,8 @@ def main(argv=None):
                      "algorithmic_bytes_per_launch":
                          JACOBI_BYTES_PER_CELL * cells * sweeps_per_launch,
                      "note": ("frac = ALGORITHMIC bytes (13 B/cell/sweep x the sweeps of a launch) / launch "
-                              "time / peak: each launch applies two Jacobi sweeps while streaming the grid "
-                              "once (temporal blocking), so it can exceed 1 (SURVEY.md 8d allows this).  "
+                              "time / peak: each launch applies sweeps_per_launch Jacobi sweeps while streaming "
+                              "the grid once (temporal blocking), so it can exceed 1 (SURVEY.md 8d allows this).  "
                               "frac_traffic = bytes the L2s requested from the fabric (TCC_EA0_RDREQ x 128 B "
                               "+ WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/) / launch time / "
                               "peak; traffic_over_single_pass_min = those bytes / one 13 B/cell pass") if fused

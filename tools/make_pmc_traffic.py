@@ -14,11 +14,12 @@ import bench  # kernel_sources_sha16
 
 src, dst = sys.argv[1], sys.argv[2]
 grid = [int(v) for v in sys.argv[3:6]]
+KERNEL = sys.argv[6] if len(sys.argv) > 6 else ("k12_canon_t" if grid[0] <= 512 else "k12_canon2")
 vals = {}
 for path in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "k12_canon2" in r["Kernel_Name"]:
+            if KERNEL + "<" in r["Kernel_Name"]:
                 vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
 avg_ns = None   # over all template variants of the kernel (the last pair of a loop is the KEEP one), like the counters
@@ -26,14 +27,14 @@ tot_ns = calls = 0.0
 for path in glob.glob(os.path.join(src, "stats", "*kernel_stats.csv")):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "k12_canon2" in r["Name"]:
+            if KERNEL + "<" in r["Name"]:
                 tot_ns += float(r["TotalDurationNs"])
                 calls += float(r["Calls"])
 if calls:
     avg_ns = tot_ns / calls
 rd = mean["TCC_EA0_RDREQ_sum"] * 128.0
 wr = mean["WRITE_SIZE"] * 1024.0
-rec = {"kernel": "k12_canon2", "grid": grid,
+rec = {"kernel": KERNEL, "grid": grid, "sweeps_per_launch": 3 if KERNEL == "k12_canon_t" else 2,
        "command": "tools/pmc_fused.sh (python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step)",
        "collected": "separate rocprofv3 --pmc passes, mean over the launches of the run",
        "TCC_EA0_RDREQ_sum": mean["TCC_EA0_RDREQ_sum"], "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
@@ -44,7 +45,7 @@ rec = {"kernel": "k12_canon2", "grid": grid,
        "avg_launch_ns_kernel_trace": avg_ns,
        "kernel_sources_sha16": bench.kernel_sources_sha16()}
 os.makedirs(dst, exist_ok=True)
-out = os.path.join(dst, f"pmc_traffic_k12_canon2_{grid[0]}x{grid[1]}x{grid[2]}.json")
+out = os.path.join(dst, f"pmc_traffic_{KERNEL}_{grid[0]}x{grid[1]}x{grid[2]}.json")
 with open(out, "w") as f:
     json.dump(rec, f, indent=1)
 print(out, json.dumps(rec))

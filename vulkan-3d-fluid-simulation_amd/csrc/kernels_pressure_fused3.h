@@ -168,6 +168,23 @@ __device__ __forceinline__ DivPairs div_pairs_rcp(uint32_t m) {
     return d;
 }
 
+// The four cells of a lane when every cell of the wavefront's row segment is a water cell with six non-solid
+// neighbours (mask word 0x06060606 in all lanes: the inside of a body of water — most of a full tank): aii and its
+// reciprocal are constants and no cell keeps its old value, which leaves the numerators and the three-instruction
+// quotients — about half the instructions of the general form.
+template <bool ZEROS_QUICK>
+__device__ __forceinline__ float4 canon_lane_all6(float4 b, float4 c, float4 yp, float4 zp, float4 ym, float4 zm,
+                                                  float left, float right) {
+    float4 n;
+    n.x = canon_num(b.x, c.y, yp.x, zp.x, left, ym.x, zm.x);
+    n.y = canon_num(b.y, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
+    n.z = canon_num(b.z, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
+    n.w = canon_num(b.w, right, yp.w, zp.w, c.z, ym.w, zm.w);
+    DivPairs d;
+    d.c[0] = d.c[1] = d.c[2] = d.c[3] = make_float2(6.0f, 0x1.555556p-3f);  // RN(1 / 6)
+    return canon_div4<ZEROS_QUICK>(n, 0x06060606u, d);
+}
+
 #ifndef FT3_LOAD_AFTER
 #define FT3_LOAD_AFTER 1
 #endif
@@ -196,6 +213,29 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
         for (int i = 0; i < RG; i++) edge[r][i] = X_EDGE_FROM_LDS ? *c.seam(buf, r, i) : c.p_oob;
     };
     lds_reads(0);
+    // Publishing for the next step — iterate j+r at plane zc+1-r into the OTHER buffer, which nobody reads in
+    // this step — can be spread over the step: ring r goes out as soon as its row exists (ring 0 after the
+    // fix-ups, ring k+1 behind stage k) instead of all rows in front of the barrier, where the wavefronts' stores
+    // queue up and the barrier waits for them: + 1.5 % at 256^3.  The two-tile kernel with three rows per
+    // wavefront sits at its 256 registers, every variant of it spills a few, and what they cost tracks the spill
+    // (8 bytes per lane: 6 770 iterations/s at 512^3; 28 bytes: 5 760): there the rows go out together, and the
+    // water test reads the mask bits (kept by the one-tile kernels too: same code).
+    constexpr bool PUBLISH_EARLY = NT == 1;
+    constexpr int nbuf = buf ^ 1;
+    auto publish = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < RG; i++) {
+            if (i == 0 || i == RG - 1 || X_EDGE_FROM_LDS) {  // rows inside a group: only across the x-tile seam
+                lds_st4(c.cells(nbuf, r, i), row[i].it[r][S2]);
+                if (WIN) {
+                    // the columns next to the window hold non-water constants: the same value in every iterate
+                    if (c.pad_writer)
+                        *c.padc(nbuf, r, i) =
+                            c.fix_pad(row[i].padv[(I + 2 - r) & 3], c.col_in && row[i].yin, zc + 1 - r);
+                }
+            }
+        }
+    };
 
     // ---- what the previous step loaded, fixed up
     const int zo = zc - (T - 1);                 // the plane stored in this step
@@ -214,6 +254,7 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
         if (c.halo_hi) ext_hi[0] = hc;
     }
 
+    if (PUBLISH_EARLY) publish(0);
     FT(0);  // LDS reads issued, wait for the previous step's loads, fix-ups
     // ---- the stages
     const uint32_t oo = (uint32_t)((zo_in ? zo : c.zb) - c.zbase) * c.plane_b;
@@ -234,33 +275,67 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
 #pragma unroll
             for (int i = 0; i < RG; i++) {
                 if (c.rr0 + i < k || c.rr0 + i > G::R - 1 - k) continue;  // wave-uniform
-                const DivPairs d = div_pairs_rcp(row[i].m[MS]);
                 const float4 ce = row[i].it[k][S1];
                 const float4 ym = i > 0 ? row[i > 0 ? i - 1 : 0].it[k][S1] : ext_lo[k];
                 const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].it[k][S1] : ext_hi[k];
                 const float left = from_lane_below(ce.w, edge[k][i], c.lane);
                 const float right = from_lane_above(ce.x, edge[k][i], c.lane);
+                // (only where registers are to spare: with three rows per wavefront the second form of the row's
+                // arithmetic costs the kernel 30 to 70 bytes of scratch per lane)
+                if (RG == 1 && __builtin_amdgcn_ballot_w64(row[i].m[MS] != 0x06060606u) == 0ull) {  // wave-uniform
+                    v[i] = canon_lane_all6<(NT >= 2)>(row[i].b[MS], ce, yp, row[i].it[k][S2], ym, row[i].it[k][S0],
+                                                      left, right);
+                    continue;
+                }
+                const DivPairs d = div_pairs_rcp(row[i].m[MS]);
+#ifdef FT3_X_NOTINY  // experiment: what the tiny-numerator test and its branch cost (wrong for |n| < 2^-100)
+                {
+                    float4 n;
+                    n.x = canon_num(row[i].b[MS].x, ce.y, yp.x, row[i].it[k][S2].x, left, ym.x, row[i].it[k][S0].x);
+                    n.y = canon_num(row[i].b[MS].y, ce.z, yp.y, row[i].it[k][S2].y, ce.x, ym.y, row[i].it[k][S0].y);
+                    n.z = canon_num(row[i].b[MS].z, ce.w, yp.z, row[i].it[k][S2].z, ce.y, ym.z, row[i].it[k][S0].z);
+                    n.w = canon_num(row[i].b[MS].w, right, yp.w, row[i].it[k][S2].w, ce.z, ym.w, row[i].it[k][S0].w);
+                    const uint32_t mm = row[i].m[MS];
+                    v[i].x = mask_is_water(mm, 0) ? div_small_int(n.x, d.c[0]) : ce.x;
+                    v[i].y = mask_is_water(mm, 1) ? div_small_int(n.y, d.c[1]) : ce.y;
+                    v[i].z = mask_is_water(mm, 2) ? div_small_int(n.z, d.c[2]) : ce.z;
+                    v[i].w = mask_is_water(mm, 3) ? div_small_int(n.w, d.c[3]) : ce.w;
+                }
+#else
                 v[i] = canon_lane<false, (NT >= 2)>(row[i].b[MS], row[i].m[MS], ce, yp, row[i].it[k][S2], ym,
                                                     row[i].it[k][S0], left, right, d);
+#endif
             }
         }
 #pragma unroll
         for (int i = 0; i < RG; i++) {
             if (k < T - 1) {
                 row[i].it[k + 1][S2] = v[i];
+                if (PUBLISH_EARLY && i == RG - 1) publish(k + 1);
             } else {
                 // stores: issued by every wavefront in every step (an exact count for the waits on the loads
                 // around them); a lane stores only if one of its four cells is water, the others — and every
-                // lane of a step outside the chunk, of a halo row — carry an offset the hardware drops
-                const uint32_t vo = wet[i] ? c.loff : FUSED3_OOB;
+                // lane of a step outside the chunk, of a halo row — carry an offset the hardware drops.
+                // The plane / row offset rides in the per-lane offset, NOT in the instruction's SGPR offset:
+                // a buffer_store_dwordx4 must not be followed at once by a VALU write to its data registers, hipcc
+                // inserts the wait state only for the forms without an SGPR offset (the ISA manual exempts the
+                // others), and on gfx950 the SGPR form needs it too — the v_cndmask of the NEXT row's offset
+                // landed in the first data register of the store just issued, and about one launch in eight
+                // came back with that offset in lanes 12-15 of each row of 16 of ONE float4 (plane 1, row 7 of
+                // the workgroup: tools/dbg_single.py).
+#ifdef FT3_X_NOSTORE  // experiment: what the stores cost
+                const uint32_t vo = FUSED3_OOB;
+#else
+                const uint32_t vo = wet[i] ? c.loff + (oo + row[i].roff4) : FUSED3_OOB;
+#endif
                 const u32x4_t bits = {__float_as_uint(v[i].x), __float_as_uint(v[i].y), __float_as_uint(v[i].z),
                                       __float_as_uint(v[i].w)};
-                __builtin_amdgcn_raw_buffer_store_b128(bits, c.ro, vo, oo + row[i].roff4, NTS ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(bits, c.ro, vo, 0, NTS ? 2 : 0);
                 if (KEEP) {  // iterate j+T-1, kept only by the last launch of a loop
                     const float4 km = row[i].it[T - 1][S1];
                     const u32x4_t kb = {__float_as_uint(km.x), __float_as_uint(km.y), __float_as_uint(km.z),
                                         __float_as_uint(km.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(kb, c.rk, vo, oo + row[i].roff4, NTS ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(kb, c.rk, vo, 0, NTS ? 2 : 0);
                 }
             }
         }
@@ -294,25 +369,14 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
         }
     }
 
-    // ---- publish the rows for the next step: iterate j+r at plane zc+1-r
-    constexpr int nbuf = buf ^ 1;
+    if (!PUBLISH_EARLY) {
 #pragma unroll
-    for (int i = 0; i < RG; i++) {
-        if (i == 0 || i == RG - 1 || X_EDGE_FROM_LDS) {
-#pragma unroll
-            for (int r = 0; r < T; r++) {
-                lds_st4(c.cells(nbuf, r, i), row[i].it[r][S2]);
-                if (WIN) {
-                    // the columns next to the window hold non-water constants: the same value in every iterate
-                    if (c.pad_writer)
-                        *c.padc(nbuf, r, i) =
-                            c.fix_pad(row[i].padv[(I + 2 - r) & 3], c.col_in && row[i].yin, zc + 1 - r);
-                }
-            }
-        }
+        for (int r = 0; r < T; r++) publish(r);
     }
     FT(4);  // publish
+#ifndef FT3_X_NOBARRIER  // experiment: what the barrier costs (wrong results)
     __syncthreads();
+#endif
     FT(5);  // barrier
 }
 
@@ -405,8 +469,9 @@ k12_canon_t(const uint8_t* __restrict__ mask, const float* __restrict__ rhs, con
     c.roff4_h = (uint32_t)__builtin_amdgcn_readfirstlane(4 * g.W * (((unsigned)yh < (unsigned)g.H) ? yh : 0));
     c.loff = 4u * xs;
     c.loff_pad = 4u * (c.col_in ? (unsigned)gxp : 0u);
-    // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4 (other lanes: harmless)
-    const int xe = c.lane == 0 ? x0 - 1 : x0 + 4;
+    // the cell across the x-tile boundary: lane 0 -> x0-1, lane 63 -> x0+4; the other lanes read along (cell
+    // tx*256 + lane: consecutive banks — their own x0+4 was a four-way bank conflict) and do not use the value
+    const int xe = c.lane == 0 ? x0 - 1 : (c.lane == 63 ? x0 + 4 : tx * 256 + c.lane);
     c.pad_writer = (c.lane == 0 && tx == 0) || (c.lane == 63 && tx == NT - 1);
     const int pad_x = c.lane == 0 ? -1 : NT * 256;
 
