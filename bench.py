@@ -596,8 +596,6 @@ def slab_rank_main(args, ranks=None):
     result = solver.benchmark(args.steps, args.warmup)
     halo = solver.stat(S.STAT_EFFECTIVE_HALO)
     rccl_ranks = solver.stat(S.STAT_RCCL_RANKS)
-    result["exchanges_per_step"] = solver.stat(S.STAT_EXCHANGES) // max(
-        args.steps + args.warmup + (6 if result["halo_overlap"].get("probed") else 0), 1)
     checksum = None
     if not args.no_checksum:
         try:

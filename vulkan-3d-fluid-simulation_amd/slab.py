@@ -615,11 +615,13 @@ class SlabDriver:
         if self.engine is not None:
             self.engine.enable_timing(True)
             self.engine.reset_timing()
+        x0 = self.stat(STAT_EXCHANGES)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         wall = time.perf_counter() - t0
+        exchanges = (self.stat(STAT_EXCHANGES) - x0) / max(steps, 1)
         ms, calls = 0.0, 0
         if self.engine is not None:
             ms, calls = self.engine.section_time_ms("12_solve_pressure")
@@ -630,39 +632,55 @@ class SlabDriver:
         wall, kernel = (float(v) for v in vals)
         w, h, _ = self.params.size
         return {"wall_s": wall, "local_cells": w * h * self.slab[1], "halo_overlap": probe,
+                "exchanges_per_step": exchanges,
                 "kernel_ms_per_sweep": kernel,
                 "exchange_ms_per_sweep": max(0.0, 1e3 * wall / (steps * self.iterations) - kernel)}
 
     def _probe_overlap(self, step) -> dict:
-        """Untimed, before the warm-up: one step with the exchanges of the Jacobi loop in line, one with
-        only the pass before each exchange split and one with both passes split, each after a step of
-        its own; every rank adopts the fastest schedule (the times are MAX over the ranks, so all agree).
-        Whether hiding an 8-MiB exchange is worth two extra launches per exchange depends on the link,
-        so it is measured where it runs.  FLUID_SLAB_OVERLAP=0 / before / 1 forces a schedule."""
+        """Untimed, before the warm-up: the exchange schedule is measured where it runs.  For each halo depth
+        (planes per exchange = sweeps between two exchanges: 8, 6 and 3 where the loop applies three sweeps per
+        launch — 3 + 3 + 2, 3 + 3 or 3 sweeps per exchange) one step with the exchanges in line, one with only
+        the pass before each exchange split and one with both passes split, each after a step of its own; every
+        rank adopts the fastest combination (the times are MAX over the ranks, so all agree).  Whether hiding an
+        exchange is worth two extra launches, and whether fewer, larger messages beat less recomputation of
+        ghost planes, depends on the link.  FLUID_SLAB_OVERLAP=0 / before / 1 forces a schedule,
+        FLUID_SLAB_HALO=h a depth."""
         import torch
         import torch.distributed as dist
 
         env = os.environ.get("FLUID_SLAB_OVERLAP")
+        env_h = os.environ.get("FLUID_SLAB_HALO")
+        if env_h is not None:
+            self.set_option(OPT_HALO_DEPTH, int(env_h))
         if env is not None:
             mode = {"0": OVERLAP_NONE, "before": OVERLAP_BEFORE}.get(env, OVERLAP_BOTH)
             self.set_option(OPT_OVERLAP, mode)
-            return {"used": mode, "probed": False}
+            return {"used": mode, "probed": False, "halo_depth": self.stat(STAT_EFFECTIVE_HALO)}
         if self.world == 1 or not dist.is_initialized():
-            return {"used": OVERLAP_NONE, "probed": False}
+            return {"used": OVERLAP_NONE, "probed": False, "halo_depth": self.stat(STAT_EFFECTIVE_HALO)}
+        thinnest = self.params.size[2] // self.world
+        depths = [int(env_h)] if env_h is not None else sorted(
+            {h for h in (8, 6, 3) if h <= min(thinnest, 8)} or {min(thinnest, 8)}, reverse=True)
         times = {}
-        for mode in (OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH):
-            self.set_option(OPT_OVERLAP, mode)
-            step()
-            self._store().sync()
-            dist.barrier()
-            t0 = time.perf_counter()
-            step()
-            self._store().sync()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            times[mode] = float(t[0])
-        best = min(times, key=times.get)
+        for h in depths:
+            self.set_option(OPT_HALO_DEPTH, h)
+            for mode in (OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH):
+                self.set_option(OPT_OVERLAP, mode)
+                step()
+                self._store().sync()
+                dist.barrier()
+                t0 = time.perf_counter()
+                step()
+                self._store().sync()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                times[(h, mode)] = float(t[0])
+        best_h, best = min(times, key=times.get)
+        self.set_option(OPT_HALO_DEPTH, best_h)
         self.set_option(OPT_OVERLAP, best)
-        return {"used": best, "probed": True, "step_ms_inline": 1e3 * times[OVERLAP_NONE],
-                "step_ms_overlap_before": 1e3 * times[OVERLAP_BEFORE],
-                "step_ms_overlapped": 1e3 * times[OVERLAP_BOTH]}
+        return {"used": best, "probed": True, "halo_depth": best_h,
+                "step_ms_inline": 1e3 * times[(best_h, OVERLAP_NONE)],
+                "step_ms_overlap_before": 1e3 * times[(best_h, OVERLAP_BEFORE)],
+                "step_ms_overlapped": 1e3 * times[(best_h, OVERLAP_BOTH)],
+                "step_ms_by_halo_depth_and_schedule": {f"h{h}_overlap{m}": round(1e3 * v, 4)
+                                                       for (h, m), v in times.items()}}
