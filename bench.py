@@ -84,6 +84,37 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def all_kernel_sources_sha16():
+    """What a whole-step counter record is valid for: every kernel source of the engine."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "vulkan-3d-fluid-simulation_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_step_traffic(n):
+    """HBM-side bytes per step of the full tank from tools/pmc_step_traffic.sh, if recorded for these sources."""
+    import glob
+    want = all_kernel_sources_sha16()
+    why = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_traffic_full_step_dense_{n}.json")),
+                       reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("all_kernel_sources_sha16") == want:
+            return rec.get("traffic_bytes_per_step"), os.path.relpath(path, ROOT)
+        why = (f"{os.path.relpath(path, ROOT)} was recorded for kernel sources "
+               f"{rec.get('all_kernel_sources_sha16')}, the build has {want}")
+    return None, why
+
+
 def recorded_traffic(kernel, size):
     """HBM-side bytes per launch of `kernel` from the PMC passes kept under profiles/ (rocprofv3 --pmc
     cannot run inside this process): (bytes, source) for this kernel and grid — but only from a record
@@ -313,11 +344,15 @@ def full_step_dense_bench(grid, iters, steps, device):
     cells = w * h * d
     step_bytes = (293.0 + 13.0 * iters) * cells + 48.0 * cap   # SURVEY.md 8d, reference layout
     shape = f"{w}^3" if w == h == d else f"{w}x{h}x{d}"
+    traffic, traffic_source = (recorded_step_traffic(w) if w == h == d and iters == 200 else (None, None))
     return {"workload": f"full tank {shape}, {cap} particles (8 per cell), {iters} Jacobi iters",
             "steps_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps,
             "algorithmic_bytes_per_step": step_bytes,
             "algorithmic_GBps": step_bytes / dt / 1e9,
             "frac_of_hbm_peak": step_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            # the physical figure: counter bytes per step (every kernel of the step) over the step time
+            "traffic": traffic, "traffic_source": traffic_source,
+            "frac_traffic": (traffic / dt / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "quiet_bricks": quiet,
             "section_ms_per_step": sections,
             "particles_per_sec": cap / dt}

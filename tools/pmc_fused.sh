@@ -12,6 +12,15 @@ BENCH="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-s
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats" -o jacobi -- $BENCH > "$ROOT/$OUT/stats.log" 2>&1
 echo "stats done"
 i=0
+if [ -n "$PMC_ONLY_TRAFFIC" ]; then   # large grids: the two passes the traffic record needs
+for c in "TCC_EA0_RDREQ_sum" "WRITE_SIZE" "FETCH_SIZE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $c --output-format csv -d "$ROOT/$OUT/pmc_$i" -o pmc -- $BENCH > "$ROOT/$OUT/pmc_$i.log" 2>&1 || echo "pass $i ($c) failed"
+    echo "pmc pass $i done: $c"
+done
+python3 $ROOT/tools/pmc_summary.py "$ROOT/$OUT" > "$ROOT/$OUT/summary.txt"
+exit 0
+fi
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "TCC_EA0_RDREQ_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum" \
          "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_sum" \

@@ -160,21 +160,25 @@ struct fluid_ctx {
     int wide_lo = 0, wide_hi = 0;
     uint64_t leavers_offset = 0;          // Leaver list of the particle migration (slab contexts)
     uint32_t leavers_capacity = 0;
-    // the owned list of a slab context (kernels_sampler.h: OwnedList), outside the arena: 2 x 4 B per slot
-    struct Owned {
-        uint32_t* slots[2] = {nullptr, nullptr};  // the list and the buffer the next squeeze writes
-        uint32_t* counters = nullptr;             // device: [0] entries appended, [1] holes made
+    // compact particle storage of a slab context (kernels_sampler.h: CompactParticles), outside the arena:
+    // 20 bytes per particle the slab holds, plus headroom
+    struct Local {
+        float4* buf[2] = {nullptr, nullptr};   // the entries and the buffer the next squeeze writes
+        uint32_t* pid[2] = {nullptr, nullptr};
+        uint32_t* counters = nullptr;          // device: [0] entries appended, [1] holes made
+        uint64_t cap = 0;     // entries buf[0] / pid[0] can hold (buf[1] / pid[1]: allocated by the first squeeze)
+        uint64_t cap2 = 0;
         uint32_t n = 0;       // entries, holes included
         uint32_t holes = 0;
-        bool valid = false;   // the list matches the particle buffer
-        bool failed = false;  // could not be allocated: every slot is looked at, as without it
-        uint64_t squeezes = 0;
-    } own;
-    OwnedList owned_list() const {
-        OwnedList o;
-        o.slots = own.valid ? own.slots[0] : nullptr;
-        o.counters = own.counters;
-        o.capacity = (uint32_t)particle_capacity;
+        bool on = false;      // this context stores its particles this way
+        uint64_t squeezes = 0, grows = 0;
+    } loc;
+    CompactParticles compact() const {
+        CompactParticles o;
+        o.buf = loc.buf[0];
+        o.pid = loc.pid[0];
+        o.counters = loc.counters;
+        o.cap = (uint32_t)loc.cap;
         return o;
     }
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
@@ -231,7 +235,8 @@ struct fluid_ctx {
         return q;
     }
     float4* particles_home() const { return reinterpret_cast<float4*>(arena + particles_offset); }
-    float4* particles() const { return ps.cur ? ps.alt : particles_home(); }  // where they are stored now
+    // where the particles are stored now (a slab context: the entries of its compact storage)
+    float4* particles() const { return loc.on ? loc.buf[0] : (ps.cur ? ps.alt : particles_home()); }
     // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
     uint8_t* mask0() const { return arena + mask_offset + (uint64_t)LOOP_GHOST * g.plane; }
     float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + LOOP_GHOST * g.plane; }
@@ -398,8 +403,9 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
         L.img_bytes[i] = plane * (uint64_t)(dl + 2 * IMG_GHOST) * kElemBytes[i];
         off = align_up(off + L.img_bytes[i], kAlign);
     }
+    const bool slab_ctx = dl != p.fluid_size[2];
     L.particles_offset = off;
-    L.particles_bytes = capacity * 16;
+    L.particles_bytes = slab_ctx ? 0 : capacity * 16;  // a slab stores what it owns, outside the arena (Local)
     off = align_up(off + L.particles_bytes, kAlign);
     L.mask_offset = off;
     off = align_up(off + plane * (uint64_t)(dl + 2 * LOOP_GHOST), kAlign);
@@ -426,12 +432,13 @@ int compute_layout(const fluid_create_info* info, const fluid_params& p, Layout&
     off = align_up(off + 256, kAlign);
     L.ghost_bricks_offset = off;
     off = align_up(off + 2 * L.active_bytes, kAlign);  // two layers would do; bytes are cheap here
-    // Four lists (send down / up, received from below / above) of capacity / 16 entries each, at least
-    // 64 Ki: 8 bytes per particle slot.  More leavers than that in one step take more hand-over rounds
+    // Four lists (send down / up, received from below / above) of a sixteenth of this slab's share of the slots
+    // each, at least 64 Ki entries.  More leavers than that in one step take more hand-over rounds
     // (fluid_particles_collect leaves them in place and says so), they are never dropped.
-    const bool slab = dl != p.fluid_size[2];
+    const bool slab = slab_ctx;
+    const uint64_t share = capacity / std::max<uint64_t>(1, p.fluid_size[2] / std::max<uint32_t>(dl, 1u));
     L.leavers_capacity =
-        slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(capacity / 16, 65536), 0x0FFFFFFFu) : 0;
+        slab ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(share / 16, 65536), 0x0FFFFFFFu) : 0;
     L.leavers_offset = off;
     off = align_up(off + 4ull * L.leavers_capacity * sizeof(Leaver), kAlign);
     L.surf_cells = 0;
@@ -933,87 +940,134 @@ int slab_unsupported(fluid_ctx* c, const char* what) {
 // FLUID_OPT_PARTICLE_SORT: 0 = on for whole-grid contexts with at least 4 M particle slots, 1 = off,
 // 2 = on whatever the size, 3 = on and sorted again before every 01 (tests), 4 = on, sorted once and never
 // again (tests: strays pile up).
-// ---- the owned list of a slab context ---------------------------------------------------------------------
-// FLUID_OPT_PARTICLE_SORT = 1 ("off": plain slot order) switches it off too.
-bool own_wanted(const fluid_ctx* c) {
-    return c->is_slab && !c->own.failed && c->particle_capacity != 0 && c->particle_capacity < 0xFFFFFFFFull &&
-           c->opt[FLUID_OPT_PARTICLE_SORT] != 1;
+// particle_owner_plane() of device_common.h, on the host
+static inline int particle_owner_plane_host(float z, int Dg) {
+    if (!(z > 0.0f)) return 0;
+    if (z >= (float)Dg) return Dg - 1;
+    return (int)z;
 }
-void own_release(fluid_ctx* c) {
-    for (auto*& q : c->own.slots)
-        if (q) (void)hipFree(q), q = nullptr;
-    if (c->own.counters) (void)hipFree(c->own.counters), c->own.counters = nullptr;
-    c->own.valid = false;
+// ---- compact particle storage of a slab context -----------------------------------------------------------
+void local_release(fluid_ctx* c) {
+    for (int i = 0; i < 2; i++) {
+        if (c->loc.buf[i]) (void)hipFree(c->loc.buf[i]), c->loc.buf[i] = nullptr;
+        if (c->loc.pid[i]) (void)hipFree(c->loc.pid[i]), c->loc.pid[i] = nullptr;
+    }
+    if (c->loc.counters) (void)hipFree(c->loc.counters), c->loc.counters = nullptr;
+    c->loc.cap = c->loc.cap2 = 0;
+    c->loc.n = c->loc.holes = 0;
 }
 // n and holes as the device has them (synchronises the stream)
-int own_read(fluid_ctx* c) {
-    if (!c->own.valid) return FLUID_OK;
+int local_read(fluid_ctx* c) {
+    if (!c->loc.on) return FLUID_OK;
     uint32_t v[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(v, c->own.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(v, c->loc.counters, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (v[0] > c->particle_capacity)  // more entries than slots: a slot listed twice, which own_* rules out
-        return c->fail(FLUID_ERR_HIP, "owned list overflow (%u entries, %llu slots)", v[0],
-                       (unsigned long long)c->particle_capacity);
-    c->own.n = v[0];
-    c->own.holes = v[1];
+    if (v[0] > c->loc.cap)  // more entries than room: local_reserve() before every append rules it out
+        return c->fail(FLUID_ERR_HIP, "particle storage overflow (%u entries, room for %llu)", v[0],
+                       (unsigned long long)c->loc.cap);
+    c->loc.n = v[0];
+    c->loc.holes = v[1];
     return FLUID_OK;
 }
-// after 00_init_particles and uploads: list what the buffer holds
-int own_rebuild(fluid_ctx* c) {
-    c->own.valid = false;
-    if (!own_wanted(c)) return FLUID_OK;
-    if (!c->own.counters) {
-        bool ok = true;
-        for (auto*& q : c->own.slots) ok = ok && hipMalloc(&q, c->particle_capacity * 4) == hipSuccess;
-        ok = ok && hipMalloc(&c->own.counters, 8) == hipSuccess;
-        if (!ok) {
-            (void)hipGetLastError();
-            own_release(c);
-            c->own.failed = true;
-            return FLUID_OK;
-        }
+// room for `need` entries in buf[0] / pid[0] (the entries there are kept); grows by half at least
+int local_reserve(fluid_ctx* c, uint64_t need) {
+    auto& L = c->loc;
+    if (!L.counters) {
+        void* q = nullptr;
+        HIP_TRY(c, hipMalloc(&q, 8));
+        L.counters = static_cast<uint32_t*>(q);
+        HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(c->own.counters, 0, 8, c->stream));
-    c->own.valid = true;  // owned_list() hands out the list from here on
-    constexpr uint64_t per_block = (uint64_t)OWNED_BLOCK * OWNED_PER_THREAD;
-    hipLaunchKernelGGL(k_owned_build, dim3((unsigned)((c->particle_capacity + per_block - 1) / per_block)),
-                       dim3(OWNED_BLOCK), 0, c->stream, c->particles(), c->particle_capacity, c->pk.active_w,
-                       c->owned_list());
-    HIP_TRY(c, hipGetLastError());
-    return own_read(c);
+    if (need <= L.cap) return FLUID_OK;
+    if (need >= 0xFFFFFFFFull) return c->fail(FLUID_ERR_UNSUPPORTED, "more than 2^32 particles in one slab");
+    const uint64_t cap = std::max<uint64_t>(need + need / 4 + 65536, L.cap + L.cap / 2);
+    void *nb = nullptr, *np = nullptr;
+    if (hipMalloc(&nb, cap * 16) != hipSuccess || hipMalloc(&np, cap * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (nb) (void)hipFree(nb);
+        return c->fail(FLUID_ERR_OUT_OF_MEMORY, "cannot grow the particle storage to %llu entries",
+                       (unsigned long long)cap);
+    }
+    if (L.n) {
+        HIP_TRY(c, hipMemcpyAsync(nb, L.buf[0], (uint64_t)L.n * 16, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(np, L.pid[0], (uint64_t)L.n * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (L.buf[0]) (void)hipFree(L.buf[0]);
+    if (L.pid[0]) (void)hipFree(L.pid[0]);
+    L.buf[0] = static_cast<float4*>(nb);
+    L.pid[0] = static_cast<uint32_t*>(np);
+    if (L.cap) L.grows++;
+    L.cap = cap;
+    return FLUID_OK;
 }
-// squeeze the holes out when they are a quarter of the list, or when `incoming` more entries would not fit
-int own_squeeze_if_needed(fluid_ctx* c, uint32_t incoming) {
-    auto& o = c->own;
-    if (!o.valid || o.holes == 0) return FLUID_OK;
-    const bool tight = (uint64_t)o.n + incoming > c->particle_capacity;
+// squeeze the holes out when they are a quarter of the entries, or when `incoming` more entries would not fit
+int local_squeeze_if_needed(fluid_ctx* c, uint32_t incoming) {
+    auto& L = c->loc;
+    if (!L.on || L.holes == 0) return FLUID_OK;
+    const bool tight = (uint64_t)L.n + incoming > L.cap;
     const bool always = c->opt[FLUID_OPT_PARTICLE_SORT] == 3;  // test mode
-    if (!tight && !always && (o.holes < 65536u || o.holes < o.n / 4u)) return FLUID_OK;
-    const uint32_t n = o.n;
-    HIP_TRY(c, hipMemsetAsync(o.counters, 0, 8, c->stream));
-    std::swap(o.slots[0], o.slots[1]);
+    if (!tight && !always && (L.holes < 65536u || L.holes < L.n / 4u)) return FLUID_OK;
+    if (L.cap2 < L.cap) {  // the second pair of arrays, as large as the first
+        if (L.buf[1]) (void)hipFree(L.buf[1]), L.buf[1] = nullptr;
+        if (L.pid[1]) (void)hipFree(L.pid[1]), L.pid[1] = nullptr;
+        void *nb = nullptr, *np = nullptr;
+        if (hipMalloc(&nb, L.cap * 16) != hipSuccess || hipMalloc(&np, L.cap * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            if (nb) (void)hipFree(nb);
+            L.cap2 = 0;
+            return FLUID_OK;  // not an error of the step: the holes stay
+        }
+        L.buf[1] = static_cast<float4*>(nb);
+        L.pid[1] = static_cast<uint32_t*>(np);
+        L.cap2 = L.cap;
+    }
+    const uint32_t n = L.n;
+    HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
+    std::swap(L.buf[0], L.buf[1]);
+    std::swap(L.pid[0], L.pid[1]);
+    std::swap(L.cap, L.cap2);
     constexpr uint32_t per_block = OWNED_BLOCK * OWNED_PER_THREAD;
-    hipLaunchKernelGGL(k_owned_compact, dim3((n + per_block - 1) / per_block), dim3(OWNED_BLOCK), 0, c->stream,
-                       o.slots[1], n, c->owned_list());
+    hipLaunchKernelGGL(k_compact_squeeze, dim3((n + per_block - 1) / per_block), dim3(OWNED_BLOCK), 0, c->stream,
+                       L.buf[1], L.pid[1], n, c->compact());
     HIP_TRY(c, hipGetLastError());
-    o.squeezes++;
-    return own_read(c);
+    L.squeezes++;
+    return local_read(c);
 }
-// entries the search for leavers looks at: the list's, or every slot
-static inline uint64_t particle_entries(const fluid_ctx* c) {
-    return c->own.valid ? c->own.n : c->particle_capacity;
+// 00_init_particles on a slab: count what it owns, make room, fill
+int local_init(fluid_ctx* c) {
+    auto& L = c->loc;
+    if (c->particle_capacity >= 0xFFFFFFFFull)
+        return c->fail(FLUID_ERR_UNSUPPORTED, "a Z-slab context numbers its particles with 32 bits");
+    L.on = true;
+    L.n = L.holes = 0;
+    int rc = local_reserve(c, 0);
+    if (rc) return rc;
+    constexpr uint64_t per_block = (uint64_t)OWNED_BLOCK * OWNED_PER_THREAD;
+    const dim3 grid((unsigned)((c->particle_capacity + per_block - 1) / per_block));
+    HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
+    CompactParticles count = c->compact();
+    count.buf = nullptr;
+    hipLaunchKernelGGL(k00_init_particles_compact, grid, dim3(OWNED_BLOCK), 0, c->stream, c->particle_capacity,
+                       c->pk, c->g, count);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t owned = 0;
+    HIP_TRY(c, hipMemcpyAsync(&owned, L.counters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = local_reserve(c, owned);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
+    hipLaunchKernelGGL(k00_init_particles_compact, grid, dim3(OWNED_BLOCK), 0, c->stream, c->particle_capacity,
+                       c->pk, c->g, c->compact());
+    HIP_TRY(c, hipGetLastError());
+    return local_read(c);
 }
-// ... and 01 and 14, which may as well walk the slots when the list names most of them (the indirection costs
-// 01 of a dam break that sits in one slab 0.45 instead of 0.39 ms): same results either way
-static inline bool walk_owned(const fluid_ctx* c) {
-    return c->own.valid && (uint64_t)c->own.n * 5u < c->particle_capacity * 4u;
-}
+// entries 01, 14 and the search for leavers look at
 static inline uint64_t walk_entries(const fluid_ctx* c) {
-    return walk_owned(c) ? c->own.n : c->particle_capacity;
+    if (c->is_slab) return c->loc.on ? c->loc.n : 0;  // (before 00_init_particles / an upload: nothing stored)
+    return c->particle_capacity;
 }
-static inline const uint32_t* walk_list(const fluid_ctx* c) {
-    return walk_owned(c) ? c->own.slots[0] : nullptr;
-}
+static inline const uint32_t* walk_list(const fluid_ctx*) { return nullptr; }
 
 bool psort_wanted(const fluid_ctx* c) {
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
@@ -1230,12 +1284,9 @@ int run_section_impl(fluid_ctx* c, int section) {
         case FLUID_SEC_00_INIT_PARTICLES:
             if (c->particle_capacity == 0) return FLUID_OK;
             psort_reset(c);  // slot order, in the arena's buffer
+            if (c->is_slab) return local_init(c);  // what this slab owns, compactly
             hipLaunchKernelGGL(k00_init_particles, dim3(pblocks), dim3(256), 0, c->stream,
-                               c->particles(), c->particle_capacity, pk, g, c->is_slab ? 1 : 0);
-            if (c->is_slab) {
-                const int rc_own = own_rebuild(c);
-                if (rc_own) return rc_own;
-            }
+                               c->particles(), c->particle_capacity, pk);
             break;
         case FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES: {
             const int rc = fill_image(c, FLUID_IMG_PARTICLE_DENSITIES_IMG, 0u);
@@ -1770,7 +1821,7 @@ void fluid_destroy(fluid_ctx* c) {
     if (c->edge_stream) (void)hipStreamDestroy(c->edge_stream);
     if (c->wide) (void)hipFree(c->wide);
     psort_release(c);
-    own_release(c);
+    local_release(c);
     if (c->blur_tmp) (void)hipFree(c->blur_tmp);
     if (c->mc_tables) (void)hipFree(c->mc_tables);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
@@ -1899,14 +1950,35 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
     }
     if (bytes) {
         psort_reset(c);  // the caller's array is in slot order
-        HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
-        if (c->is_slab) {  // the caller passes the global array: keep what this slab owns
-            const unsigned blocks = (unsigned)((c->particle_capacity + 255) / 256);
-            hipLaunchKernelGGL(k_particles_filter, dim3(blocks), dim3(256), 0, c->stream,
-                               c->particles(), c->particle_capacity, c->g);
-            const int rc_own = own_rebuild(c);
-            if (rc_own) return rc_own;
+        if (c->is_slab) {
+            // the caller passes the global array: this slab keeps what it owns, compactly (host-side selection —
+            // an upload is no hot path, and the device never holds a slot per particle of the run)
+            const float4* src = static_cast<const float4*>(host);
+            std::vector<float4> keep;
+            std::vector<uint32_t> ids;
+            for (uint64_t i = 0; i < c->particle_capacity; i++) {
+                const int pl = particle_owner_plane_host(src[i].z, c->g.Dg) - c->g.z0;
+                if ((unsigned)pl < (unsigned)c->g.Dl) {
+                    keep.push_back(src[i]);
+                    ids.push_back((uint32_t)i);
+                }
+            }
+            auto& L = c->loc;
+            L.on = true;
+            L.n = L.holes = 0;
+            int rc2 = local_reserve(c, keep.size());
+            if (rc2) return rc2;
+            if (!keep.empty()) {
+                HIP_TRY(c, hipMemcpyAsync(L.buf[0], keep.data(), keep.size() * 16, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(L.pid[0], ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+            }
+            const uint32_t counters[2] = {(uint32_t)keep.size(), 0u};
+            HIP_TRY(c, hipMemcpyAsync(L.counters, counters, 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vectors go out of scope
+            L.n = counters[0];
+            return FLUID_OK;
         }
+        HIP_TRY(c, hipMemcpyAsync(c->particles(), host, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return FLUID_OK;
@@ -1932,6 +2004,29 @@ int fluid_download_buffer(fluid_ctx* c, int buffer_id, void* host, uint64_t byte
         HIP_TRY(c, hipMemcpyAsync(host, c->mc_tables + (is_counts ? 0 : 256), bytes, hipMemcpyDeviceToHost,
                                   c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return FLUID_OK;
+    }
+    if (bytes && c->is_slab) {
+        // the global array: the slots this slab holds with their data, a tombstone in every other one
+        float4* out = static_cast<float4*>(host);
+        float4 tomb;
+        tomb.x = tomb.y = tomb.z = 0.f;
+        const uint32_t tb = PARTICLE_TOMBSTONE_BITS;
+        memcpy(&tomb.w, &tb, 4);
+        for (uint64_t i = 0; i < c->particle_capacity; i++) out[i] = tomb;
+        const uint32_t n = c->loc.on ? c->loc.n : 0u;
+        if (n) {
+            std::vector<float4> data(n);
+            std::vector<uint32_t> ids(n);
+            HIP_TRY(c, hipMemcpyAsync(data.data(), c->loc.buf[0], (uint64_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(ids.data(), c->loc.pid[0], (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (uint32_t k = 0; k < n; k++) {
+                uint32_t w;
+                memcpy(&w, &data[k].w, 4);
+                if (w != PARTICLE_TOMBSTONE_BITS && ids[k] < c->particle_capacity) out[ids[k]] = data[k];
+            }
+        }
         return FLUID_OK;
     }
     if (bytes) {
@@ -2751,10 +2846,10 @@ int fluid_get_stat(fluid_ctx* c, int stat, uint64_t* value) {
             *value = c->ps.binned ? 1 : 0;
             return FLUID_OK;
         case FLUID_STAT_PARTICLE_ENTRIES:
-            *value = particle_entries(c);
+            *value = walk_entries(c);
             return FLUID_OK;
         case FLUID_STAT_OWNED_SQUEEZES:
-            *value = c->own.squeezes;
+            *value = c->loc.squeezes;
             return FLUID_OK;
         case FLUID_STAT_PARTICLE_STRAYS: {
             uint32_t v[2] = {0, 0};
@@ -2925,17 +3020,17 @@ int fluid_particles_collect(fluid_ctx* c, int reset_lists, uint32_t counts[2], u
     if (!c->is_slab || c->particle_capacity == 0) return FLUID_OK;
     if (reset_lists) {
         HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));
-        const int rc_own = own_squeeze_if_needed(c, 0);  // once per step: the holes of the steps before
+        const int rc_own = local_squeeze_if_needed(c, 0);  // once per step: the holes of the steps before
         if (rc_own) return rc_own;
     }
-    const uint64_t n = particle_entries(c);
+    const uint32_t n = c->loc.on ? c->loc.n : 0u;
     if (n) {
-        hipLaunchKernelGGL(k_particles_collect_leavers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           c->stream, c->particles(), n, c->g, c->migrate_lists(), c->owned_list());
+        hipLaunchKernelGGL(k_particles_collect_leavers, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                           c->loc.buf[0], c->loc.pid[0], n, c->g, c->migrate_lists(), c->loc.counters);
         HIP_TRY(c, hipGetLastError());
     }
     int rc = read_migrate_counts(c, counts, left_behind);
-    if (rc == FLUID_OK) rc = own_read(c);
+    if (rc == FLUID_OK) rc = local_read(c);
     return rc;
 }
 
@@ -2948,22 +3043,23 @@ int fluid_particles_adopt_received(fluid_ctx* c, uint32_t from_below, uint32_t f
                        from_above, c->leavers_capacity);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->flags() + 28, 0, 8, c->stream));  // the send lists have been sent
-    {   // room for what may be adopted (a slot is listed at most once, so without holes it always fits)
-        const int rc_own = own_squeeze_if_needed(c, from_below + from_above);
+    if (!c->loc.on) return c->fail(FLUID_ERR_INVALID_ARG, "no particle storage yet: 00_init_particles or an upload first");
+    {   // room for what may be adopted: squeeze the holes out if that makes it, grow the arrays otherwise
+        int rc_own = local_squeeze_if_needed(c, from_below + from_above);
+        if (rc_own == FLUID_OK) rc_own = local_reserve(c, (uint64_t)c->loc.n + from_below + from_above);
         if (rc_own) return rc_own;
     }
     const uint32_t n[2] = {from_below, from_above};
     for (int src = 0; src < 2; src++) {
         if (n[src] == 0) continue;
         // from below: travelling up (dir 1); from above: travelling down (dir 0)
-        hipLaunchKernelGGL(k_particles_adopt, dim3((n[src] + 255) / 256), dim3(256), 0, c->stream,
-                           c->particles(), c->particle_capacity, c->g, c->leavers(2 + src), n[src],
-                           src == 0 ? 1 : 0, c->migrate_lists(), c->owned_list(), c->pk.active_w);
+        hipLaunchKernelGGL(k_particles_adopt, dim3((n[src] + 255) / 256), dim3(256), 0, c->stream, c->g,
+                           c->leavers(2 + src), n[src], src == 0 ? 1 : 0, c->migrate_lists(), c->compact());
         HIP_TRY(c, hipGetLastError());
     }
     uint32_t over = 0;
     int rc = read_migrate_counts(c, forwarded, &over);
-    if (rc == FLUID_OK) rc = own_read(c);
+    if (rc == FLUID_OK) rc = local_read(c);
     if (rc) return rc;
     if (over)  // cannot happen while every rank's lists have the same capacity (forwarded <= received)
         return c->fail(FLUID_ERR_OUT_OF_MEMORY, "%u forwarded particles did not fit the send lists", over);

@@ -466,8 +466,8 @@ __global__ void k_max_abs_vz(const float4* __restrict__ v1, int64_t cells, uint3
 }
 
 // 14_particles/particles.comp:45-51
-// owned (Z-slab contexts, optional): the slots of the particles this slab holds, `capacity` entries of which
-// some are OWNED_HOLE (see "the owned list" below); without it every slot of the buffer is looked at
+// owned (optional): a list of `capacity` slots to look at, of which some are OWNED_HOLE, instead of every slot
+// of the buffer (Z-slab contexts store their particles compactly now and pass none)
 constexpr uint32_t OWNED_HOLE = 0xFFFFFFFFu;
 __global__ void k14_particles(const float4* __restrict__ v1, float4* __restrict__ particles,
                               uint64_t capacity, GridK g, ParamsK p,
@@ -503,12 +503,6 @@ __device__ __forceinline__ bool slab_owns(const GridK& g, float z) {
 __device__ __forceinline__ float4 tombstone() {
     return make_float4(0.f, 0.f, 0.f, __uint_as_float(PARTICLE_TOMBSTONE_BITS));
 }
-// after an upload of the global particle array: keep the slots this slab owns, bury the rest
-__global__ void k_particles_filter(float4* __restrict__ particles, uint64_t capacity, GridK g) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
-    if (!slab_owns(g, particles[i].z)) particles[i] = tombstone();
-}
 // A "leaver": a particle this slab holds but no longer owns (14_particles moved it across a face).
 // Hand-over is between Z-neighbours: a leaver travels down (towards z = 0) or up, its new owner adopts
 // it, and a slab that receives one it does not own either (the particle crossed more than one slab in a
@@ -532,49 +526,36 @@ __device__ __forceinline__ bool migrate_append(const MigrateLists& m, int dir, f
     m.send[dir][slot] = l;
     return true;
 }
-// The owned list (Z-slab contexts): 01, 14 and the search for leavers would otherwise read every slot of a
-// buffer sized for the particles of ALL slabs, on every rank, every step.  The list holds the slots of the
-// active particles this slab owns; a particle that leaves turns its entry into OWNED_HOLE, one that is adopted
-// is appended, and the host squeezes the holes out when they pile up (engine.hip: own_*).  The order of the
-// entries means nothing: 01's counts are integer atomics and 14 treats every particle on its own.
-struct OwnedList {
-    uint32_t* slots;    // entries
-    uint32_t* counters; // [0] entries appended so far, [1] holes made so far
-    uint32_t capacity;  // entries the list can hold
+// Compact storage (Z-slab contexts): a slab stores the particles it OWNS — buf[0 .. n) with the slot (the index
+// of the global particle array, which is what the API, the hand-over lists and 00_init_particles speak) of each
+// one beside it — instead of a slot for every particle of the run with tombstones in the others' (8-way full
+// tank at 512^3: 1.05 G slots on every rank for 132 M owned).  01, 14 and the search for leavers walk the n
+// entries; a particle that leaves turns its entry into a tombstone (a hole), one that is adopted is appended;
+// the host squeezes the holes out when they pile up and grows the arrays when an adoption would not fit
+// (engine.hip: local_*).  The order of the entries means nothing: 01's counts are integer atomics and 14 treats
+// every particle on its own.
+struct CompactParticles {
+    float4* buf;         // entries; null: count only
+    uint32_t* pid;       // slot of each entry
+    uint32_t* counters;  // [0] entries appended so far, [1] holes made so far
+    uint32_t cap;        // entries the arrays can hold
 };
-// append the slots of the lanes that want to, one atomic per wavefront, the lanes' entries in lane order
-__device__ __forceinline__ void owned_append(const OwnedList& o, bool want, uint32_t slot) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
-    if (m == 0ull) return;
-    const int lane = (int)(threadIdx.x & 63u), leader = __builtin_ctzll(m);
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(o.counters, (uint32_t)__builtin_popcountll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (want) {
-        const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (pos < o.capacity) o.slots[pos] = slot;  // counters[0] > capacity tells the host (never: see own_*)
-    }
-}
-// Building and squeezing keep slot order inside a block's 4096 candidates (one atomic per block; the blocks'
-// runs land in any order): 01 folds the particles of 4096 consecutive entries in an LDS table before it
-// touches the image, which pays when they share cells — particles of neighbouring slots do (they were spawned
-// side by side), particles of 64 unrelated wavefront-sized runs do not (01 of a dam break, all of it in one
-// slab: 0.39 ms over every slot, 0.63 ms over a list appended wavefront by wavefront).
+// Appending keeps candidate order inside a block's 4096 candidates (one atomic per block; the blocks' runs land
+// in any order): 01 folds the particles of 4096 consecutive entries in an LDS table before it touches the image,
+// which pays when they share cells — particles of neighbouring slots do (they were spawned side by side).
 constexpr int OWNED_BLOCK = 256, OWNED_PER_THREAD = 16;
-template <typename Candidate>
-__device__ __forceinline__ void owned_append_block(const OwnedList& o, uint64_t n, Candidate candidate) {
-    // candidate(i, slot) -> does entry i of the block's range go into the list, and with which slot
+template <typename Wants, typename Fetch>
+__device__ __forceinline__ void compact_append_block(const CompactParticles& o, uint64_t n, Wants wants, Fetch fetch) {
+    // wants(i) -> does candidate i of the block's range go into the arrays; fetch(i, data, slot) -> with what
     __shared__ uint32_t part[OWNED_PER_THREAD][OWNED_BLOCK / 64];
     __shared__ uint32_t block_base;
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const uint64_t base = (uint64_t)blockIdx.x * (OWNED_BLOCK * OWNED_PER_THREAD);
-    uint32_t slot[OWNED_PER_THREAD];
     unsigned long long mask[OWNED_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < OWNED_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * OWNED_BLOCK + threadIdx.x;
-        slot[k] = OWNED_HOLE;
-        const bool want = i < n && candidate(i, slot[k]);
+        const bool want = i < n && wants(i);
         mask[k] = __builtin_amdgcn_ballot_w64(want);
         if (lane == 0) part[k][wave] = (uint32_t)__builtin_popcountll(mask[k]);
     }
@@ -590,62 +571,54 @@ __device__ __forceinline__ void owned_append_block(const OwnedList& o, uint64_t 
         block_base = total ? atomicAdd(o.counters, total) : 0u;
     }
     __syncthreads();
+    if (!o.buf) return;  // counting pass
 #pragma unroll
     for (int k = 0; k < OWNED_PER_THREAD; k++) {
         if ((mask[k] >> lane) & 1ull) {
             const uint32_t pos = block_base + part[k][wave] +
                                  (uint32_t)__builtin_popcountll(mask[k] & ((1ull << lane) - 1ull));
-            if (pos < o.capacity) o.slots[pos] = slot[k];
+            if (pos < o.cap) {  // counters[0] > cap tells the host (never: it sizes the arrays first)
+                const uint64_t i = base + (uint64_t)k * OWNED_BLOCK + threadIdx.x;
+                float4 data;
+                uint32_t slot;
+                fetch(i, data, slot);
+                o.buf[pos] = data;
+                o.pid[pos] = slot;
+            }
         }
     }
 }
-// after 00 and after uploads: list the active particles the buffer holds (the others' slots are tombstones)
+// squeeze the holes out: (src, src_pid, n entries) -> o
 __global__ void __launch_bounds__(OWNED_BLOCK)
-k_owned_build(const float4* __restrict__ particles, uint64_t capacity, float active_w, OwnedList o) {
-    owned_append_block(o, capacity, [&](uint64_t i, uint32_t& slot) {
-        slot = (uint32_t)i;
-        return particles[i].w == active_w;
-    });
-}
-// squeeze the holes out: src (n entries) -> o
-__global__ void __launch_bounds__(OWNED_BLOCK)
-k_owned_compact(const uint32_t* __restrict__ src, uint32_t n, OwnedList o) {
-    owned_append_block(o, n, [&](uint64_t i, uint32_t& slot) {
-        slot = src[i];
-        return slot != OWNED_HOLE;
-    });
+k_compact_squeeze(const float4* __restrict__ src, const uint32_t* __restrict__ src_pid, uint32_t n,
+                  CompactParticles o) {
+    compact_append_block(
+        o, n, [&](uint64_t i) { return !is_tombstone(src[i]); },
+        [&](uint64_t i, float4& data, uint32_t& slot) {
+            data = src[i];
+            slot = src_pid[i];
+        });
 }
 
-// list the particles this slab holds but does not own and bury their slots; a particle that finds its
-// list full stays where it is (the host runs another round).  With an owned list: `capacity` of its entries
-// are looked at instead of every slot.
-__global__ void k_particles_collect_leavers(float4* __restrict__ particles, uint64_t capacity,
-                                            GridK g, MigrateLists m, OwnedList o) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
-    const uint64_t entry = i;
-    if (o.slots) {
-        const uint32_t slot = o.slots[entry];
-        if (slot == OWNED_HOLE) return;
-        i = slot;
-    }
-    const float4 q = particles[i];
+// list the particles this slab holds but no longer owns and bury their entries; a particle that finds its
+// list full stays where it is (the host runs another round)
+__global__ void k_particles_collect_leavers(float4* __restrict__ buf, const uint32_t* __restrict__ pid, uint32_t n,
+                                            GridK g, MigrateLists m, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = buf[i];
     if (is_tombstone(q)) return;
     const int pl = particle_owner_plane(q.z, g.Dg) - g.z0;
     if ((unsigned)pl < (unsigned)g.Dl) return;
-    if (migrate_append(m, pl < 0 ? 0 : 1, q, (uint32_t)i)) {
-        particles[i] = tombstone();
-        if (o.slots) {
-            o.slots[entry] = OWNED_HOLE;
-            atomicAdd(o.counters + 1, 1u);
-        }
+    if (migrate_append(m, pl < 0 ? 0 : 1, q, pid[i])) {
+        buf[i] = tombstone();
+        atomicAdd(counters + 1, 1u);
     }
 }
 // entries received from the neighbour below travel up (dir 1), those from above travel down (dir 0):
-// adopt what this slab owns, pass the rest on
-__global__ void k_particles_adopt(float4* __restrict__ particles, uint64_t capacity, GridK g,
-                                  const Leaver* __restrict__ list, uint32_t count, int dir,
-                                  MigrateLists m, OwnedList o, float active_w) {
+// adopt (append) what this slab owns, pass the rest on
+__global__ void k_particles_adopt(GridK g, const Leaver* __restrict__ list, uint32_t count, int dir,
+                                  MigrateLists m, CompactParticles o) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool adopted = false;
     Leaver l;
@@ -653,23 +626,29 @@ __global__ void k_particles_adopt(float4* __restrict__ particles, uint64_t capac
     l.data = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < count) {
         l = list[i];
-        if (l.index < capacity) {
-            if (slab_owns(g, l.data.z)) {
-                particles[l.index] = l.data;
-                adopted = l.data.w == active_w;
-            } else {
-                migrate_append(m, dir, l.data, l.index);
-            }
+        if (slab_owns(g, l.data.z))
+            adopted = true;
+        else
+            migrate_append(m, dir, l.data, l.index);
+    }
+    // one atomic per wavefront, the lanes' entries in lane order
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(adopted);
+    if (mask == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u), leader = __builtin_ctzll(mask);
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(o.counters, (uint32_t)__builtin_popcountll(mask));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (adopted) {
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (pos < o.cap) {
+            o.buf[pos] = l.data;
+            o.pid[pos] = l.index;
         }
     }
-    if (o.slots) owned_append(o, adopted, l.index);
 }
 
-// 00_init_particles/init_particles.comp:27-50
-__global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capacity, ParamsK p,
-                                   GridK g, int slab) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
+// particle i of 00_init_particles/init_particles.comp:27-50
+__device__ __forceinline__ float4 spawned_particle(uint64_t i, const ParamsK& p) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // :48
     if (i < (uint64_t)p.spawn_volume) {          // :39
         uint32_t n = (uint32_t)i;                // getPos :27-34
@@ -684,8 +663,24 @@ __global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capa
         o.z = p.spawn_offset[2] + ((1.0f * (float)cz) / (float)p.spawn_res[2]) * p.spawn_size[2];
         o.w = p.active_w;  // :45
     }
-    if (slab && !slab_owns(g, o.z)) o = tombstone();
-    particles[i] = o;
+    return o;
+}
+// 00 on a Z slab: the particles of the run this slab owns, appended (o.buf null: counted)
+__global__ void __launch_bounds__(OWNED_BLOCK)
+k00_init_particles_compact(uint64_t capacity, ParamsK p, GridK g, CompactParticles o) {
+    compact_append_block(
+        o, capacity, [&](uint64_t i) { return slab_owns(g, spawned_particle(i, p).z); },
+        [&](uint64_t i, float4& data, uint32_t& slot) {
+            data = spawned_particle(i, p);
+            slot = (uint32_t)i;
+        });
+}
+
+// 00_init_particles/init_particles.comp:27-50
+__global__ void k00_init_particles(float4* __restrict__ particles, uint64_t capacity, ParamsK p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    particles[i] = spawned_particle(i, p);
 }
 
 // ivec3(pos.xyz) truncates toward zero; the imageAtomicAdd is dropped outside the image
