@@ -414,11 +414,13 @@ int fluid_notify_ghost_planes_written(fluid_ctx* ctx, int image_id);
  * violation flag (fluid_slab_status reads and clears it) and the pass is redone with more of them
  * (fluid_sampler_* below).  include/fluid_slab.h drives all of this.
  *
- * Particles: every rank holds the full-capacity buffer; global particle i lives in slot i of the rank
- * whose slab contains the plane the particle counts towards (01_update_densities), the other ranks
- * hold a tombstone there (w = bit pattern 0x7FC0DEAD).  fluid_upload_buffer(PARTICLES_BUF) takes the
- * global array and keeps the owned slots.  After 14 the particles that left the slab are handed to the
- * Z-neighbours (fluid_particles_* below). */
+ * Particles: global particle i (slot i of the API's particle array) lives on the rank whose slab contains
+ * the plane the particle counts towards (01_update_densities).  A rank STORES only what it owns — the
+ * particles and their slots side by side, outside the arena: 20 bytes per owned particle plus headroom,
+ * growing when an adoption would not fit —; fluid_upload_buffer(PARTICLES_BUF) takes the global array and
+ * keeps the owned slots, fluid_download_buffer returns the global array with a tombstone (w = bit pattern
+ * 0x7FC0DEAD) in every slot this rank does not hold.  After 14 the particles that left the slab are handed
+ * to the Z-neighbours (fluid_particles_* below). */
 #define FLUID_IMAGE_GHOST_PLANES 4
 int fluid_slab_status(fluid_ctx* ctx, uint32_t* halo_violation);
 
@@ -555,9 +557,8 @@ typedef enum fluid_option {
                                    /* slots (default; needs 28 B per slot outside the arena, falls back to slot */
                                    /* order if that cannot be allocated), 1 = off, 2 = on at any size; 3 / 4 =   */
                                    /* test modes (sort before every 01 / sort once and never again).            */
-                                   /* Z-slab contexts keep slot order and list the slots of the particles they  */
-                                   /* own instead (the buffer has a slot for every particle of every slab):     */
-                                   /* 1 = no list, every slot is read; any other value = list                   */
+                                   /* Z-slab contexts store the particles they own compactly, in no particular  */
+                                   /* order, whatever the value (3: holes are squeezed out at once; tests)      */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
@@ -599,10 +600,10 @@ typedef enum fluid_stat {
     FLUID_STAT_PARTICLE_STRAYS = 3,  /* particles the last 01 found outside the bin they are stored in     */
     FLUID_STAT_PARTICLE_BINNED = 4,  /* 1 while 01 and 14 run on bins; 0 in slot order or while the flow    */
                                      /* moves the particles faster than sorting pays (tried again later)    */
-    FLUID_STAT_PARTICLE_ENTRIES = 5, /* Z-slab contexts: entries (holes included) of the list of particles the */
-                                     /* slab owns, which the search for leavers walks, and 01 and 14 too unless */
-                                     /* it names more than 4/5 of the slots; otherwise the number of slots      */
-    FLUID_STAT_OWNED_SQUEEZES = 6    /* times that list had its holes squeezed out                          */
+    FLUID_STAT_PARTICLE_ENTRIES = 5, /* Z-slab contexts: entries (holes included) of the compact storage of the   */
+                                     /* particles the slab owns, which 01, 14 and the search for leavers walk;  */
+                                     /* whole-grid contexts: the number of slots                                */
+    FLUID_STAT_OWNED_SQUEEZES = 6    /* times that storage had its holes squeezed out                       */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 

@@ -3,6 +3,10 @@
  *
  *     q0 = n * r;  e = fma(-q0, a, n);  q = fma(e, r, q0)      with r = RN(1/a)
  *
+ * and of the same chain with r one ulp BELOW RN(1/a) where 1/a is not a power of two — what v_rcp_f32 returns on
+ * gfx950 for a = 3 and 6 (kernels_pressure_fused3.h takes its reciprocals from that instruction;
+ * tools/micro/rcp_small_int.hip prints them) —
+ *
  * against the IEEE division n / a of pressure.comp:62, bit for bit, for a = 1..6 and every fp32 n that
  * v_div_fixup_f32 passes through (finite, non-zero).  The kernel takes this path only when all |n| of
  * a wavefront are >= 2^-90 (GUARD below), so mismatches below the guard are reported but allowed.
@@ -31,8 +35,14 @@ static int differs(uint32_t u, float a, float r) {
 int main(int argc, char** argv) {
     const int full = argc > 1 && strcmp(argv[1], "full") == 0;
     unsigned long long above = 0, below = 0, checked = 0;
+    for (int pass = 0; pass < 2; pass++)
     for (int ai = 1; ai <= 6; ai++) {
-        const float a = (float)ai, r = 1.0f / a;
+        const float a = (float)ai;
+        float r = 1.0f / a;
+        if (pass == 1) {  // the reciprocal one ulp below RN(1/a): only where they can differ
+            if (ai == 1 || ai == 2 || ai == 4) continue;
+            r = as_f(as_u(r) - 1u);
+        }
         unsigned long long bad_above = 0, bad_below = 0, cnt = 0;
 #pragma omp parallel for reduction(+ : bad_above, bad_below, cnt) schedule(static)
         for (long long i = 0; i < (1LL << 32); i++) {

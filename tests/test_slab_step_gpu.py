@@ -74,9 +74,9 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     sim.attach_torch_transport(device_memory=True)
     if world == 3:   # one workgroup per brick layer in the skipping passes, as on grids of >= 4096 bricks
         sim.engine.set_option(E.OPT_QUIET_BRICKS, 2)
-        # ... and the list of owned particles squeezed whenever it has a hole (by itself: from 65536 holes on)
+        # ... and the compact particle storage squeezed whenever it has a hole (by itself: from 65536 holes on)
         sim.engine.set_option(E.OPT_PARTICLE_SORT, 3)
-    if plain_slots:  # no list of owned particles: 01, 14 and the search for leavers read every slot
+    if plain_slots:  # (once: every slot of the run on every rank; the storage is compact whatever the option now)
         sim.engine.set_option(E.OPT_PARTICLE_SORT, 1)
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
@@ -123,7 +123,7 @@ def _check(got, world, size, iters, steps, intended=False, fast=0.0):
     (2, (30, 24, 16), 12, 4, True, False, False),   # width not a multiple of 4
     (2, (32, 24, 16), 12, 4, True, True, False),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
     (3, (64, 32, 48), 8, 60, True, False, False),  # a long run: the block collapses across both faces and spreads
-    (2, (32, 24, 16), 12, 6, True, False, True),   # without the list of owned particles
+    (2, (32, 24, 16), 12, 6, True, False, True),   # FLUID_OPT_PARTICLE_SORT = 1
 ])
 def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, plain_slots, tmp_path):
     import torch.multiprocessing as mp
@@ -135,10 +135,11 @@ def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, inte
                        nprocs=world, join=True, start_method="spawn")
     got = np.load(os.path.join(str(tmp_path), "result.npz"))
     st = _check(got, world, size, iters, steps, intended)
-    # 01, 14 and the search for leavers looked at the particles a slab owns, not at every slot of the buffer
+    # a slab stores (and 01, 14 and the search for leavers look at) the particles it owns, not a slot per particle of
+    # the run: the largest storage of the ranks holds fewer entries than the run has particles
     _, cap = scene_params(size, intended)
     entries, squeezes = int(got["stats"][9]), int(got["stats"][10])
-    assert entries == cap if plain_slots else 0 < entries < cap, (entries, cap)
+    assert 0 < entries < cap, (entries, cap)
     if world == 3:
         assert squeezes > 0
     # the scene did what the test is for: water on both sides of a face, particles changed owner

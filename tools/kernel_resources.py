@@ -8,7 +8,8 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-
 KEYS = (("TotalSGPRs", "sgpr"), ("VGPRs", "vgpr"), (r"ScratchSize \[bytes/lane\]", "scratch"),
         (r"Occupancy \[waves/SIMD\]", "occ"), (r"LDS Size \[bytes/block\]", "lds"))
 order, d = [], {}
-for unit in ("engine", "pressure_sweep", "pressure_fused", "pressure_fused_win", "pressure_fused_stream", "pressure_passes"):
+for unit in ("engine", "pressure_sweep", "pressure_fused", "pressure_fused_win", "pressure_fused_stream", "pressure_fused3",
+             "pressure_passes"):
     out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", "-o",
                           "/dev/null", unit + ".hip"], cwd=CSRC, capture_output=True, text=True).stderr
     cur = None

@@ -41,7 +41,9 @@ static hipError_t launch3(hipStream_t s, const uint8_t* mask, const float* rhs, 
             const char* e = getenv("FLUID_FUSED_RG");
             return e ? atoi(e) : 0;
         }();
-        const bool thin = forced ? forced == 1 : small_box_launch(g, rg, box, FusedGeomT<1, 3, 3>::TY);
+        // (windowed launches: always — the windowed three-row kernel does not fit its 256 registers, 92 to 140 bytes
+        // of scratch per lane)
+        const bool thin = WIN || (forced ? forced == 1 : small_box_launch(g, rg, box, FusedGeomT<1, 3, 3>::TY));
         if (thin)
             return launch_nt<1, WIN, 1, 3>(s, mask, rhs, pin, pout, pmid, bricks, g, p_oob, rg, box, part, part_lo,
                                            part_hi);
