@@ -1,9 +1,10 @@
 # dev: variants of the three-sweep kernel at 512^3 / 256^3: rebuild pressure_fused3.o with a flag set each
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-t3e}; mkdir -p $OUT
-q() { for G in "512" "256"; do python3 bench.py --grid $G --steps 4 --warmup 2 --no-cpu-baseline --no-full-step 2> $OUT/b.err | python3 -c "
+q() { for G in "512" "512 512 128" "256"; do python3 bench.py --grid $G --steps 4 --warmup 2 --no-cpu-baseline --no-full-step 2> $OUT/b.err | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 grid $G', round(d['value'],1), 'it/s', round(d['roofline']['ms_per_sweep'],4), 'ms/sweep')"; done; }
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
-for x in "" "-DFT3_PUBLISH_LATE" "-DFT3_WATER_BITS" "-DFT3_PUBLISH_LATE -DFT3_WATER_BITS" "-DFT3_LOAD_AFTER=2" "-DFT3_LOAD_AFTER=2 -DFT3_PUBLISH_LATE"; do
+for x in "-DFT3_NO_FORMS"; do
   (cd vulkan-3d-fluid-simulation_amd/csrc && touch pressure_fused3.hip && make HIPFLAGS="$FL $x" > $OUT/make.log 2>&1 || tail -3 $OUT/make.log)
   q "[$x]"
 done
+timeout -k 10 600 python -m pytest tests/test_engine_parity_gpu.py -x -q -k "pressure" > $OUT/tests.log 2>&1; echo "rc=$?" >> $OUT/tests.log; tail -3 $OUT/tests.log

@@ -271,7 +271,12 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
             any = any || (forms && (k < T - 1 ? mask_any_water(row[i].m[MS]) : wet[i]));
             v[i] = row[i].it[k][S1];  // cells that are not water (and rows that do not form this stage) keep theirs
         }
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        // The launches of the fat kernels (several rows per wavefront) are the dense ones: there a stage without
+        // a water cell in any of the wavefront's rows is rare, and the wave-uniform test for it costs more than
+        // it saves (a branch and its merge per stage: 512^3 6 820 -> 7 270 iterations/s without it; dry cells
+        // keep their values through the selects either way).  The thin kernels (sparse scenes) keep it.
+        constexpr bool skip_test = RG >= 2;
+        if (skip_test || __builtin_amdgcn_ballot_w64(any) != 0ull) {
 #pragma unroll
             for (int i = 0; i < RG; i++) {
                 if (c.rr0 + i < k || c.rr0 + i > G::R - 1 - k) continue;  // wave-uniform
@@ -280,31 +285,16 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
                 const float4 yp = i < RG - 1 ? row[i < RG - 1 ? i + 1 : 0].it[k][S1] : ext_hi[k];
                 const float left = from_lane_below(ce.w, edge[k][i], c.lane);
                 const float right = from_lane_above(ce.x, edge[k][i], c.lane);
-                // (only where registers are to spare: with three rows per wavefront the second form of the row's
-                // arithmetic costs the kernel 30 to 70 bytes of scratch per lane)
+                // (thin kernels only: in the fat ones the extra wave-uniform branch per row and stage costs more than
+                // the shorter arithmetic saves — 512^3 7 250 -> 6 100 iterations/s — although it fits the registers)
                 if (RG == 1 && __builtin_amdgcn_ballot_w64(row[i].m[MS] != 0x06060606u) == 0ull) {  // wave-uniform
                     v[i] = canon_lane_all6<(NT >= 2)>(row[i].b[MS], ce, yp, row[i].it[k][S2], ym, row[i].it[k][S0],
                                                       left, right);
                     continue;
                 }
                 const DivPairs d = div_pairs_rcp(row[i].m[MS]);
-#ifdef FT3_X_NOTINY  // experiment: what the tiny-numerator test and its branch cost (wrong for |n| < 2^-100)
-                {
-                    float4 n;
-                    n.x = canon_num(row[i].b[MS].x, ce.y, yp.x, row[i].it[k][S2].x, left, ym.x, row[i].it[k][S0].x);
-                    n.y = canon_num(row[i].b[MS].y, ce.z, yp.y, row[i].it[k][S2].y, ce.x, ym.y, row[i].it[k][S0].y);
-                    n.z = canon_num(row[i].b[MS].z, ce.w, yp.z, row[i].it[k][S2].z, ce.y, ym.z, row[i].it[k][S0].z);
-                    n.w = canon_num(row[i].b[MS].w, right, yp.w, row[i].it[k][S2].w, ce.z, ym.w, row[i].it[k][S0].w);
-                    const uint32_t mm = row[i].m[MS];
-                    v[i].x = mask_is_water(mm, 0) ? div_small_int(n.x, d.c[0]) : ce.x;
-                    v[i].y = mask_is_water(mm, 1) ? div_small_int(n.y, d.c[1]) : ce.y;
-                    v[i].z = mask_is_water(mm, 2) ? div_small_int(n.z, d.c[2]) : ce.z;
-                    v[i].w = mask_is_water(mm, 3) ? div_small_int(n.w, d.c[3]) : ce.w;
-                }
-#else
                 v[i] = canon_lane<false, (NT >= 2)>(row[i].b[MS], row[i].m[MS], ce, yp, row[i].it[k][S2], ym,
                                                     row[i].it[k][S0], left, right, d);
-#endif
             }
         }
 #pragma unroll
@@ -323,11 +313,7 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
                 // landed in the first data register of the store just issued, and about one launch in eight
                 // came back with that offset in lanes 12-15 of each row of 16 of ONE float4 (plane 1, row 7 of
                 // the workgroup: tools/dbg_single.py).
-#ifdef FT3_X_NOSTORE  // experiment: what the stores cost
-                const uint32_t vo = FUSED3_OOB;
-#else
                 const uint32_t vo = wet[i] ? c.loff + (oo + row[i].roff4) : FUSED3_OOB;
-#endif
                 const u32x4_t bits = {__float_as_uint(v[i].x), __float_as_uint(v[i].y), __float_as_uint(v[i].z),
                                       __float_as_uint(v[i].w)};
                 __builtin_amdgcn_raw_buffer_store_b128(bits, c.ro, vo, 0, NTS ? 2 : 0);
@@ -374,9 +360,7 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
         for (int r = 0; r < T; r++) publish(r);
     }
     FT(4);  // publish
-#ifndef FT3_X_NOBARRIER  // experiment: what the barrier costs (wrong results)
     __syncthreads();
-#endif
     FT(5);  // barrier
 }
 
