@@ -1,6 +1,5 @@
 """Dev tool: one rank of an N-way Z-slab run of the FULL TANK (8 particles per cell everywhere), neighbours
-played by itself (loopback), with the list of owned particles and without: what reading every slot of a
-particle buffer sized for all slabs costs 01 and 14 on each rank.
+played by itself (loopback): the step of a middle rank, section by section, and the size of its particle storage.
     python tools/slab_dense_rank_step.py [grid=512] [ranks=8] [iters=200]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +17,7 @@ p.particle_spawn_cube_volume = cap
 p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
 p.particle_spawn_cube_size[:] = size
 rank = ranks // 2
-for mode, name in ((0, "list of owned particles"), (1, "every slot            ")):
+for mode, name in ((0, "compact storage"),):
     with S.SlabDriver(p, rank, ranks, particle_capacity=cap, pressure_iterations=iters, device=0) as drv:
         drv.engine.set_option(E.OPT_PARTICLE_SORT, mode)
         drv.attach_loopback(True, True)
@@ -37,6 +36,6 @@ for mode, name in ((0, "list of owned particles"), (1, "every slot            ")
             drv.run_step()
         drv.engine.sync()
         t = drv.engine.section_times()
-        sec = {k: round(v[0] / 2, 3) for k, v in t.items() if v[1] and k[:2] in ("01", "14")}
+        sec = {k[:24]: round(v[0] / 2, 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0]) if v[1] and v[0] / 2 >= 0.05}
         print(f"rank {rank} of {ranks}, full tank {n}^3, {cap} slots, {name}: {ms:8.3f} ms/step   "
               f"entries {drv.engine.get_stat(E.STAT_PARTICLE_ENTRIES)}   {sec}")

@@ -919,9 +919,10 @@ int run_fast_loop(fluid_ctx* c, uint32_t iterations) {
     // wants fluid_run_step to stay fully asynchronous turns it off (FLUID_OPT_LAUNCH_BOX = 1)
     if (rc == FLUID_OK && most >= 2 && iterations >= 16 && c->opt[FLUID_OPT_LAUNCH_BOX] == 0)
         rc = refresh_box(c);
+    const uint32_t most_here = (most == 3 && !k12_canon3_suits(c->g, c->box)) ? 2u : most;
     while (rc == FLUID_OK && c->loop_k < iterations) {
         const uint32_t left = iterations - c->loop_k;
-        const uint32_t sweeps = next_launch_sweeps(left, most);
+        const uint32_t sweeps = next_launch_sweeps(left, most_here);
         rc = loop_advance(c, sweeps, sweeps >= 2 && left == sweeps, nullptr);
     }
     if (rc) return rc;

@@ -86,6 +86,9 @@ hipError_t k12_launch_canon3(hipStream_t s, const uint8_t* mask, const float* rh
                              float p_oob, int halo_lo, int halo_hi, int aux_lo, int aux_hi,
                              const ActiveBox& box, int part = 0, int part_lo = 0, int part_hi = 0);
 bool k12_canon3_supports(const GridK& g);
+// ... and is the better launch shape for this box of water (whole-grid contexts decide per loop; the ranks of a
+// Z-slab run must agree and go by the grid alone)
+bool k12_canon3_suits(const GridK& g, const ActiveBox& box);
 // one red-black SOR iteration (colour 0 then colour 1) in one pass over HBM: work[src] -> work[dst]
 hipError_t k12_launch_canon2_sor(hipStream_t s, const uint8_t* mask, const float* rhs, const float* pin,
                                  float* pout, const uint8_t* bricks, const GridK& g, float p_oob,

@@ -10,6 +10,24 @@ namespace fluid {
 // of W x H floats at most): H <= 4096.
 bool k12_canon3_supports(const GridK& g) { return g.W % 4 == 0 && g.W <= 512 && g.H <= 4096 && g.Dl >= 3; }
 
+// Is a launch of three sweeps the better shape for this box of water?  One x tile (a narrow grid, or a window
+// around the water): yes — the thin three-sweep kernel exists.  Two tiles: only the fat shape exists (three rows on
+// 8 wavefronts), which a launch over a small box loses with (few workgroups, each slow): the 512^3 dam break once
+// the water has spread over more than 256 columns ran its loop 7 % slower than with pairs on 16 thin wavefronts.
+bool k12_canon3_suits(const GridK& g, const ActiveBox& box) {
+    if (!box.valid) return true;
+    const int nt = (g.W + 255) / 256;
+    if (nt == 1) return true;
+    if (box.x_hi > box.x_lo) {
+        const int x0 = box.x_lo & ~31;
+        if ((box.x_hi - x0 + 255) / 256 == 1) return true;
+    }
+    FusedRange rg{};
+    rg.zout_lo = 0;
+    rg.zout_hi = g.Dl;
+    return !small_box_launch(g, rg, box, FusedGeomT<2, 3, 3>::TY);
+}
+
 template <int NT, int RG, bool KEEP>
 hipError_t k12_launch_streaming3(const FusedLaunchArgs& a) {
     using G = FusedGeomT<NT, RG, 3>;
