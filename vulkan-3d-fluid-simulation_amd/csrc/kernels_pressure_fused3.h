@@ -151,23 +151,11 @@ struct FusedCtxT {
     }
 };
 
-// The (aii, reciprocal) pairs of a lane's four cells without the LDS table of kernels_pressure_fused.h: aii by
-// v_cvt_f32_ubyte, the reciprocal by v_rcp_f32.  On gfx950 v_rcp_f32 returns RN(1 / a) for a = 1, 2, 4, 5 and the
-// truncated value (one ulp below) for a = 3 and 6 (tools/micro/rcp_small_int.hip; the GPU suite checks it);
-// tests/divide_small_int_check.c proves the quotient chain of div_small_int exact for all |n| >= 2^-125 with
-// either value.  A table look-up per row and stage was a dependent LDS round trip on the wavefront's critical
-// path: nine per plane step.
-__device__ __forceinline__ DivPairs div_pairs_rcp(uint32_t m) {
-    DivPairs d;
-    const float a0 = (float)(m & 0xFFu), a1 = (float)((m >> 8) & 0xFFu), a2 = (float)((m >> 16) & 0xFFu),
-                a3 = (float)(m >> 24);
-    d.c[0] = make_float2(a0, __builtin_amdgcn_rcpf(a0));
-    d.c[1] = make_float2(a1, __builtin_amdgcn_rcpf(a1));
-    d.c[2] = make_float2(a2, __builtin_amdgcn_rcpf(a2));
-    d.c[3] = make_float2(a3, __builtin_amdgcn_rcpf(a3));
-    return d;
-}
-
+// The reciprocals of the quotient n / aii (canon_lane_pk below) come from v_cvt_f32_ubyte + v_rcp_f32, not from the LDS
+// table of kernels_pressure_fused.h: a table look-up per row and stage was a dependent LDS round trip on the
+// wavefront's critical path, nine per plane step.  On gfx950 v_rcp_f32 returns RN(1 / a) for a = 1, 2, 4, 5 and the
+// truncated value (one ulp below) for a = 3 and 6 (tools/micro/rcp_small_int.hip; tests/test_rcp_gpu.py checks it);
+// tests/divide_small_int_check.c proves the quotient chain of div_small_int exact for all |n| >= 2^-125 with either.
 // The four cells of a lane when every cell of the wavefront's row segment is a water cell with six non-solid
 // neighbours (mask word 0x06060606 in all lanes: the inside of a body of water — most of a full tank): aii and its
 // reciprocal are constants and no cell keeps its old value, which leaves the numerators and the three-instruction
@@ -183,6 +171,68 @@ __device__ __forceinline__ float4 canon_lane_all6(float4 b, float4 c, float4 yp,
     DivPairs d;
     d.c[0] = d.c[1] = d.c[2] = d.c[3] = make_float2(6.0f, 0x1.555556p-3f);  // RN(1 / 6)
     return canon_div4<ZEROS_QUICK>(n, 0x06060606u, d);
+}
+
+// canon_lane of kernels_pressure_fused.h on pairs of cells: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on two
+// floats per lane in the four cycles one v_add_f32 takes a wavefront (this is where the chip's fp32 vector peak comes
+// from: 16 lanes per SIMD and clock, two floats each), each element rounded as the scalar instruction rounds it — so
+// the six subtractions and the three-instruction quotient of a lane's four cells take half the instructions, bit for
+// bit the same.  The x neighbours of cells (0, 1) and (2, 3) are the pairs (left, c.x), (c.y, c.z), (c.w, right).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool ZEROS_QUICK>
+__device__ __forceinline__ float4 canon_lane_pk(float4 b, uint32_t m, float4 c, float4 yp, float4 zp, float4 ym,
+                                                float4 zm, float left, float right) {
+    const f32x2_t w0 = {left, c.x}, w1 = {c.y, c.z}, w2 = {c.w, right};
+    f32x2_t s01 = {b.x, b.y}, s23 = {b.z, b.w};
+    s01 = s01 - w1;                      // + x   (pressure.comp:56-61 order: +x, +y, +z, -x, -y, -z)
+    s23 = s23 - w2;
+    s01 = s01 - (f32x2_t){yp.x, yp.y};   // + y
+    s23 = s23 - (f32x2_t){yp.z, yp.w};
+    s01 = s01 - (f32x2_t){zp.x, zp.y};   // + z
+    s23 = s23 - (f32x2_t){zp.z, zp.w};
+    s01 = s01 - w0;                      // - x
+    s23 = s23 - w1;
+    s01 = s01 - (f32x2_t){ym.x, ym.y};   // - y
+    s23 = s23 - (f32x2_t){ym.z, ym.w};
+    s01 = s01 - (f32x2_t){zm.x, zm.y};   // - z
+    s23 = s23 - (f32x2_t){zm.z, zm.w};
+    const f32x2_t n01 = -s01, n23 = -s23;
+    const float a0 = (float)(m & 0xFFu), a1 = (float)((m >> 8) & 0xFFu), a2 = (float)((m >> 16) & 0xFFu),
+                a3 = (float)(m >> 24);
+    float4 o;
+    auto quick = [&]() {
+        const f32x2_t a01 = {a0, a1}, a23 = {a2, a3};
+        const f32x2_t r01 = {__builtin_amdgcn_rcpf(a0), __builtin_amdgcn_rcpf(a1)},
+                      r23 = {__builtin_amdgcn_rcpf(a2), __builtin_amdgcn_rcpf(a3)};
+        const f32x2_t p01 = n01 * r01, p23 = n23 * r23;  // div_small_int, two cells at a time
+        const f32x2_t e01 = __builtin_elementwise_fma(-p01, a01, n01), e23 = __builtin_elementwise_fma(-p23, a23, n23);
+        const f32x2_t q01 = __builtin_elementwise_fma(e01, r01, p01), q23 = __builtin_elementwise_fma(e23, r23, p23);
+        o.x = __builtin_amdgcn_div_fixupf(q01.x, a0, n01.x);
+        o.y = __builtin_amdgcn_div_fixupf(q01.y, a1, n01.y);
+        o.z = __builtin_amdgcn_div_fixupf(q23.x, a2, n23.x);
+        o.w = __builtin_amdgcn_div_fixupf(q23.y, a3, n23.y);
+    };
+    // the tiny-numerator test of canon_div4 (kernels_pressure_fused.h)
+    const float least = fminf(fminf(fabsf(n01.x), fabsf(n01.y)), fminf(fabsf(n23.x), fabsf(n23.y)));
+    bool slow = __builtin_amdgcn_ballot_w64(least < 0x1p-100f) != 0ull;
+    if (slow && ZEROS_QUICK) {
+        const int ex = min(min(__builtin_amdgcn_frexp_expf(n01.x), __builtin_amdgcn_frexp_expf(n01.y)),
+                           min(__builtin_amdgcn_frexp_expf(n23.x), __builtin_amdgcn_frexp_expf(n23.y)));
+        slow = __builtin_amdgcn_ballot_w64(ex < -99) != 0ull;  // only zeros were small: quick
+    }
+    if (!slow) {
+        quick();
+    } else {  // some 0 < |n| < 2^-100 in this wavefront: the IEEE sequence for all its lanes
+        o.x = n01.x / a0;
+        o.y = n01.y / a1;
+        o.z = n23.x / a2;
+        o.w = n23.y / a3;
+    }
+    o.x = mask_is_water(m, 0) ? o.x : c.x;  // non-water (and out-of-grid) cells keep their constant
+    o.y = mask_is_water(m, 1) ? o.y : c.y;
+    o.z = mask_is_water(m, 2) ? o.z : c.z;
+    o.w = mask_is_water(m, 3) ? o.w : c.w;
+    return o;
 }
 
 #ifndef FT3_LOAD_AFTER
@@ -292,9 +342,8 @@ __device__ __forceinline__ void fused_step_t(const FusedCtxT<NT, RG, T>& c, Fuse
                                                       left, right);
                     continue;
                 }
-                const DivPairs d = div_pairs_rcp(row[i].m[MS]);
-                v[i] = canon_lane<false, (NT >= 2)>(row[i].b[MS], row[i].m[MS], ce, yp, row[i].it[k][S2], ym,
-                                                    row[i].it[k][S0], left, right, d);
+                v[i] = canon_lane_pk<(NT >= 2)>(row[i].b[MS], row[i].m[MS], ce, yp, row[i].it[k][S2], ym,
+                                                row[i].it[k][S0], left, right);
             }
         }
 #pragma unroll
