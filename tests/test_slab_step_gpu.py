@@ -76,8 +76,9 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
         sim.engine.set_option(E.OPT_QUIET_BRICKS, 2)
         # ... and the compact particle storage squeezed whenever it has a hole (by itself: from 65536 holes on)
         sim.engine.set_option(E.OPT_PARTICLE_SORT, 3)
-    if plain_slots:  # (once: every slot of the run on every rank; the storage is compact whatever the option now)
-        sim.engine.set_option(E.OPT_PARTICLE_SORT, 1)
+    if plain_slots:  # FLUID_OPT_PARTICLE_SORT: 1 = the compact storage is never sorted by bin; 2 = sorted whatever its
+        # size (by itself: from 4 M entries); 4 = sorted once and never again (strays and adopted particles pile up)
+        sim.engine.set_option(E.OPT_PARTICLE_SORT, int(plain_slots))
     sim.run_init()
     sim.run_step()  # cells become active first: velocities of newly active faces are replaced (05)
     sim.upload_image_global(E.VELOCITIES_1, drift((size[2], size[1], size[0]), fast))
@@ -90,7 +91,8 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     out["particles"] = sim.gather_particles()
     t = torch.tensor([sim.stat(i) for i in range(8)] + [sim.engine.get_stat(E.STAT_QUIET_BRICKS),
                                                         sim.engine.get_stat(E.STAT_PARTICLE_ENTRIES),
-                                                        sim.engine.get_stat(E.STAT_OWNED_SQUEEZES)],
+                                                        sim.engine.get_stat(E.STAT_OWNED_SQUEEZES),
+                                                        sim.engine.get_stat(E.STAT_PARTICLE_SORTS)],
                      dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -123,7 +125,10 @@ def _check(got, world, size, iters, steps, intended=False, fast=0.0):
     (2, (30, 24, 16), 12, 4, True, False, False),   # width not a multiple of 4
     (2, (32, 24, 16), 12, 4, True, True, False),   # 09_diffuse in intended mode: V2 ghost planes, no 09+10+11 group
     (3, (64, 32, 48), 8, 60, True, False, False),  # a long run: the block collapses across both faces and spreads
-    (2, (32, 24, 16), 12, 6, True, False, True),   # FLUID_OPT_PARTICLE_SORT = 1
+    (2, (32, 24, 16), 12, 6, True, False, 1),   # FLUID_OPT_PARTICLE_SORT = 1: never sorted
+    (2, (32, 24, 16), 12, 6, True, False, 2),   # sorted by bin when the policy says so
+    (2, (32, 24, 16), 12, 8, True, False, 4),   # sorted once: leavers leave holes, the adopted sit behind the bins
+    (3, (64, 32, 48), 8, 30, True, False, 4),   # ... over a run in which the block collapses across both faces
 ])
 def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, intended, plain_slots, tmp_path):
     import torch.multiprocessing as mp
@@ -140,8 +145,13 @@ def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, inte
     _, cap = scene_params(size, intended)
     entries, squeezes = int(got["stats"][9]), int(got["stats"][10])
     assert 0 < entries < cap, (entries, cap)
-    if world == 3:
-        assert squeezes > 0
+    sorts = int(got["stats"][11])
+    if world == 3 and not plain_slots:   # mode 3: sorted before every 01 (a sort drops the holes: no squeeze is needed)
+        assert sorts >= steps and squeezes == 0
+    if plain_slots == 1:
+        assert sorts == 0
+    if plain_slots in (2, 4):
+        assert sorts >= 1
     # the scene did what the test is for: water on both sides of a face, particles changed owner
     d = size[2]
     face = d // world

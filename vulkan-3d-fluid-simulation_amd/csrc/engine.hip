@@ -163,22 +163,25 @@ struct fluid_ctx {
     // compact particle storage of a slab context (kernels_sampler.h: CompactParticles), outside the arena:
     // 20 bytes per particle the slab holds, plus headroom
     struct Local {
-        float4* buf[2] = {nullptr, nullptr};   // the entries and the buffer the next squeeze writes
-        uint32_t* pid[2] = {nullptr, nullptr};
+        float4* buf[2] = {nullptr, nullptr};   // two sets of arrays: the entries live in set `cur`, a squeeze or
+        uint32_t* pid[2] = {nullptr, nullptr}; // a sort writes them into the other one
+        uint64_t capn[2] = {0, 0};             // entries each set can hold
+        int cur = 0;
         uint32_t* counters = nullptr;          // device: [0] entries appended, [1] holes made
-        uint64_t cap = 0;     // entries buf[0] / pid[0] can hold (buf[1] / pid[1]: allocated by the first squeeze)
-        uint64_t cap2 = 0;
-        uint32_t n = 0;       // entries, holes included
+        uint32_t n = 0;         // entries, holes included
         uint32_t holes = 0;
-        bool on = false;      // this context stores its particles this way
+        uint32_t n_sorted = 0;  // while ps.binned: entries [0, n_sorted) are in bin order (ps.bin_start), the
+                                // rest was adopted since the sort
+        uint64_t strays_cap = 0;
+        bool on = false;        // this context stores its particles this way
         uint64_t squeezes = 0, grows = 0;
     } loc;
     CompactParticles compact() const {
         CompactParticles o;
-        o.buf = loc.buf[0];
-        o.pid = loc.pid[0];
+        o.buf = loc.buf[loc.cur];
+        o.pid = loc.pid[loc.cur];
         o.counters = loc.counters;
-        o.cap = (uint32_t)loc.cap;
+        o.cap = (uint32_t)loc.capn[loc.cur];
         return o;
     }
     bool mask_valid = false;      // mask + bricks match CELL_TYPES and the cell type values
@@ -236,7 +239,7 @@ struct fluid_ctx {
     }
     float4* particles_home() const { return reinterpret_cast<float4*>(arena + particles_offset); }
     // where the particles are stored now (a slab context: the entries of its compact storage)
-    float4* particles() const { return loc.on ? loc.buf[0] : (ps.cur ? ps.alt : particles_home()); }
+    float4* particles() const { return loc.on ? loc.buf[loc.cur] : (ps.cur ? ps.alt : particles_home()); }
     // owned plane 0 of the loop's arrays (LOOP_GHOST ghost planes in front of it)
     uint8_t* mask0() const { return arena + mask_offset + (uint64_t)LOOP_GHOST * g.plane; }
     float* rhs0() const { return reinterpret_cast<float*>(arena + rhs_offset) + LOOP_GHOST * g.plane; }
@@ -952,10 +955,11 @@ void local_release(fluid_ctx* c) {
     for (int i = 0; i < 2; i++) {
         if (c->loc.buf[i]) (void)hipFree(c->loc.buf[i]), c->loc.buf[i] = nullptr;
         if (c->loc.pid[i]) (void)hipFree(c->loc.pid[i]), c->loc.pid[i] = nullptr;
+        c->loc.capn[i] = 0;
     }
     if (c->loc.counters) (void)hipFree(c->loc.counters), c->loc.counters = nullptr;
-    c->loc.cap = c->loc.cap2 = 0;
-    c->loc.n = c->loc.holes = 0;
+    c->loc.n = c->loc.holes = c->loc.n_sorted = 0;
+    c->loc.cur = 0;
 }
 // n and holes as the device has them (synchronises the stream)
 int local_read(fluid_ctx* c) {
@@ -963,14 +967,42 @@ int local_read(fluid_ctx* c) {
     uint32_t v[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(v, c->loc.counters, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (v[0] > c->loc.cap)  // more entries than room: local_reserve() before every append rules it out
+    if (v[0] > c->loc.capn[c->loc.cur])  // more entries than room: local_reserve() before every append rules it out
         return c->fail(FLUID_ERR_HIP, "particle storage overflow (%u entries, room for %llu)", v[0],
-                       (unsigned long long)c->loc.cap);
+                       (unsigned long long)c->loc.capn[c->loc.cur]);
     c->loc.n = v[0];
     c->loc.holes = v[1];
     return FLUID_OK;
 }
-// room for `need` entries in buf[0] / pid[0] (the entries there are kept); grows by half at least
+// set `which` of the arrays with room for `need` entries; keep = its first L.n entries survive a reallocation
+int local_set_reserve(fluid_ctx* c, int which, uint64_t need, bool keep) {
+    auto& L = c->loc;
+    if (need <= L.capn[which]) return FLUID_OK;
+    if (need >= 0xFFFFFFFFull) return c->fail(FLUID_ERR_UNSUPPORTED, "more than 2^32 particles in one slab");
+    const uint64_t cap = std::max<uint64_t>(need + need / 4 + 65536, L.capn[which] + L.capn[which] / 2);
+    void *nb = nullptr, *np = nullptr;
+    if (hipMalloc(&nb, cap * 16) != hipSuccess || hipMalloc(&np, cap * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (nb) (void)hipFree(nb);
+        return c->fail(FLUID_ERR_OUT_OF_MEMORY,
+                       "cannot grow the particle storage to %llu entries (%llu asked for; set %d holds %u of %llu)",
+                       (unsigned long long)cap, (unsigned long long)need, which, L.n,
+                       (unsigned long long)L.capn[which]);
+    }
+    if (keep && L.n) {
+        HIP_TRY(c, hipMemcpyAsync(nb, L.buf[which], (uint64_t)L.n * 16, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(np, L.pid[which], (uint64_t)L.n * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // nothing in flight reads the old arrays any more
+    if (L.buf[which]) (void)hipFree(L.buf[which]);
+    if (L.pid[which]) (void)hipFree(L.pid[which]);
+    L.buf[which] = static_cast<float4*>(nb);
+    L.pid[which] = static_cast<uint32_t*>(np);
+    if (L.capn[which]) L.grows++;
+    L.capn[which] = cap;
+    return FLUID_OK;
+}
+// room for `need` entries in the current set (the entries there are kept, in their order); grows by half at least
 int local_reserve(fluid_ctx* c, uint64_t need) {
     auto& L = c->loc;
     if (!L.counters) {
@@ -979,58 +1011,27 @@ int local_reserve(fluid_ctx* c, uint64_t need) {
         L.counters = static_cast<uint32_t*>(q);
         HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
     }
-    if (need <= L.cap) return FLUID_OK;
-    if (need >= 0xFFFFFFFFull) return c->fail(FLUID_ERR_UNSUPPORTED, "more than 2^32 particles in one slab");
-    const uint64_t cap = std::max<uint64_t>(need + need / 4 + 65536, L.cap + L.cap / 2);
-    void *nb = nullptr, *np = nullptr;
-    if (hipMalloc(&nb, cap * 16) != hipSuccess || hipMalloc(&np, cap * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        if (nb) (void)hipFree(nb);
-        return c->fail(FLUID_ERR_OUT_OF_MEMORY, "cannot grow the particle storage to %llu entries",
-                       (unsigned long long)cap);
-    }
-    if (L.n) {
-        HIP_TRY(c, hipMemcpyAsync(nb, L.buf[0], (uint64_t)L.n * 16, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(np, L.pid[0], (uint64_t)L.n * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    if (L.buf[0]) (void)hipFree(L.buf[0]);
-    if (L.pid[0]) (void)hipFree(L.pid[0]);
-    L.buf[0] = static_cast<float4*>(nb);
-    L.pid[0] = static_cast<uint32_t*>(np);
-    if (L.cap) L.grows++;
-    L.cap = cap;
-    return FLUID_OK;
+    return local_set_reserve(c, L.cur, need, true);
 }
-// squeeze the holes out when they are a quarter of the entries, or when `incoming` more entries would not fit
+// squeeze the holes out when they are a quarter of the entries, or when `incoming` more entries would not fit.
+// Sorted storage (ps.binned) keeps its holes — the next sort drops them — unless room is needed now.
 int local_squeeze_if_needed(fluid_ctx* c, uint32_t incoming) {
     auto& L = c->loc;
     if (!L.on || L.holes == 0) return FLUID_OK;
-    const bool tight = (uint64_t)L.n + incoming > L.cap;
+    const bool tight = (uint64_t)L.n + incoming > L.capn[L.cur];
     const bool always = c->opt[FLUID_OPT_PARTICLE_SORT] == 3;  // test mode
-    if (!tight && !always && (L.holes < 65536u || L.holes < L.n / 4u)) return FLUID_OK;
-    if (L.cap2 < L.cap) {  // the second pair of arrays, as large as the first
-        if (L.buf[1]) (void)hipFree(L.buf[1]), L.buf[1] = nullptr;
-        if (L.pid[1]) (void)hipFree(L.pid[1]), L.pid[1] = nullptr;
-        void *nb = nullptr, *np = nullptr;
-        if (hipMalloc(&nb, L.cap * 16) != hipSuccess || hipMalloc(&np, L.cap * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            if (nb) (void)hipFree(nb);
-            L.cap2 = 0;
-            return FLUID_OK;  // not an error of the step: the holes stay
-        }
-        L.buf[1] = static_cast<float4*>(nb);
-        L.pid[1] = static_cast<uint32_t*>(np);
-        L.cap2 = L.cap;
-    }
+    if (!tight && (c->ps.binned || (!always && (L.holes < 65536u || L.holes < L.n / 4u)))) return FLUID_OK;
+    const int other = L.cur ^ 1;
+    if (local_set_reserve(c, other, L.n, false) != FLUID_OK) return FLUID_OK;  // not an error: the holes stay
     const uint32_t n = L.n;
     HIP_TRY(c, hipMemsetAsync(L.counters, 0, 8, c->stream));
-    std::swap(L.buf[0], L.buf[1]);
-    std::swap(L.pid[0], L.pid[1]);
-    std::swap(L.cap, L.cap2);
+    const float4* src = L.buf[L.cur];
+    const uint32_t* src_pid = L.pid[L.cur];
+    L.cur = other;
+    c->ps.binned = false;  // (the order survives a squeeze, the bins' segment starts do not)
     constexpr uint32_t per_block = OWNED_BLOCK * OWNED_PER_THREAD;
     hipLaunchKernelGGL(k_compact_squeeze, dim3((n + per_block - 1) / per_block), dim3(OWNED_BLOCK), 0, c->stream,
-                       L.buf[1], L.pid[1], n, c->compact());
+                       src, src_pid, n, c->compact());
     HIP_TRY(c, hipGetLastError());
     L.squeezes++;
     return local_read(c);
@@ -1041,7 +1042,8 @@ int local_init(fluid_ctx* c) {
     if (c->particle_capacity >= 0xFFFFFFFFull)
         return c->fail(FLUID_ERR_UNSUPPORTED, "a Z-slab context numbers its particles with 32 bits");
     L.on = true;
-    L.n = L.holes = 0;
+    L.n = L.holes = L.n_sorted = 0;
+    L.cur = 0;
     int rc = local_reserve(c, 0);
     if (rc) return rc;
     constexpr uint64_t per_block = (uint64_t)OWNED_BLOCK * OWNED_PER_THREAD;
@@ -1070,12 +1072,13 @@ static inline uint64_t walk_entries(const fluid_ctx* c) {
 }
 static inline const uint32_t* walk_list(const fluid_ctx*) { return nullptr; }
 
+// particles the sorted storage is about: every slot of a whole-grid context, the entries of a slab's storage
+static inline uint64_t psort_n(const fluid_ctx* c) { return c->is_slab ? c->loc.n : c->particle_capacity; }
 bool psort_wanted(const fluid_ctx* c) {
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
-    if (c->is_slab || c->ps.failed || c->particle_capacity == 0 || c->particle_capacity >= (1ull << 32) ||
-        mode == 1)
-        return false;
-    return mode >= 2 || c->particle_capacity >= (1ull << 22);
+    if (c->ps.failed || c->particle_capacity == 0 || c->particle_capacity >= (1ull << 32) || mode == 1) return false;
+    if (c->is_slab && !c->loc.on) return false;
+    return mode >= 2 || psort_n(c) >= (1ull << 22);
 }
 void psort_release(fluid_ctx* c) {
     auto& ps = c->ps;
@@ -1103,6 +1106,44 @@ void psort_reset(fluid_ctx* c) {
 }
 bool psort_alloc(fluid_ctx* c) {
     auto& ps = c->ps;
+    if (c->is_slab) {
+        // a slab sorts its compact storage between its two sets of arrays (Local); here: the bins (of its OWN
+        // planes), the strays list (as many entries as the storage holds) and the small words
+        auto& L = c->loc;
+        void* q = nullptr;
+        bool ok = true;
+        if (!ps.bin_count) {
+            ps.bk.nx = (c->g.W + PBIN_X - 1) / PBIN_X;
+            ps.bk.ny = (c->g.H + PBIN_Y - 1) / PBIN_Y;
+            ps.bk.nz = (c->g.Dl + PBIN_Z - 1) / PBIN_Z;
+            ps.bk.bins = (uint32_t)ps.bk.nx * (uint32_t)ps.bk.ny * (uint32_t)ps.bk.nz;
+            const uint64_t words = (uint64_t)ps.bk.bins + 2;
+            if ((ok = hipMalloc(&q, 3 * words * 4) == hipSuccess)) {
+                ps.bin_count = static_cast<uint32_t*>(q);
+                ps.bin_start = ps.bin_count + words;
+                ps.cursor = ps.bin_start + words;
+            }
+            if (ok && (ok = hipMalloc(&q, 8) == hipSuccess)) ps.stray_count = static_cast<uint32_t*>(q);
+            if (ok && (ok = hipHostMalloc(&q, 8, hipHostMallocDefault) == hipSuccess))
+                ps.stray_host = static_cast<uint32_t*>(q);
+            if (ok) ok = hipEventCreateWithFlags(&ps.stray_ev, hipEventDisableTiming) == hipSuccess;
+        }
+        if (ok && L.strays_cap < L.capn[L.cur]) {
+            if (ps.stray_pending) (void)hipStreamSynchronize(c->stream), ps.stray_pending = false;
+            if (ps.strays) (void)hipStreamSynchronize(c->stream), (void)hipFree(ps.strays), ps.strays = nullptr;
+            if ((ok = hipMalloc(&q, L.capn[L.cur] * 4) == hipSuccess)) {
+                ps.strays = static_cast<uint32_t*>(q);
+                L.strays_cap = L.capn[L.cur];
+            }
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            psort_release(c);
+            L.strays_cap = 0;
+            ps.failed = true;
+        }
+        return ok;
+    }
     if (ps.alt) return true;
     ps.bk.nx = (c->g.W + PBIN_X - 1) / PBIN_X;
     ps.bk.ny = (c->g.H + PBIN_Y - 1) / PBIN_Y;
@@ -1135,6 +1176,43 @@ bool psort_alloc(fluid_ctx* c) {
 }
 int psort_sort(fluid_ctx* c) {
     auto& ps = c->ps;
+    if (c->is_slab) {
+        // the entries of the current set into the other one in bin order, their slots with them; the holes
+        // (tombstones) are not taken along, so the count afterwards is what the scan added up
+        auto& L = c->loc;
+        const uint64_t n = L.n, per_block = (uint64_t)PSORT_THREADS * PSORT_PER_THREAD;
+        const int other = L.cur ^ 1;
+        int rc = local_set_reserve(c, other, n, false);  // (n, not the other set's room: the sets would leapfrog)
+        if (rc) return rc;
+        if (!psort_alloc(c)) return FLUID_OK;  // (strays list as large as the storage)
+        HIP_TRY(c, hipMemsetAsync(ps.bin_count, 0, ((uint64_t)ps.bk.bins + 2) * 4, c->stream));
+        if (n) {
+            hipLaunchKernelGGL(k_pbin_histogram, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(PSORT_THREADS),
+                               0, c->stream, L.buf[L.cur], n, c->g, c->pk, ps.bk, ps.bin_count, true);
+        }
+        hipLaunchKernelGGL(k_pbin_scan, dim3(1), dim3(1024), 0, c->stream, ps.bin_count, ps.bk.bins + 1, ps.bin_start,
+                           ps.cursor);
+        if (n) {
+            const uint64_t per_block2 = (uint64_t)PSORT_THREADS * PSCATTER_PER_THREAD;
+            hipLaunchKernelGGL(k_pbin_scatter, dim3((unsigned)((n + per_block2 - 1) / per_block2)), dim3(PSORT_THREADS),
+                               0, c->stream, L.buf[L.cur], L.pid[L.cur], n, c->g, c->pk, ps.bk, ps.cursor, L.buf[other],
+                               L.pid[other], true);
+        }
+        HIP_TRY(c, hipGetLastError());
+        // entries now: bin_start[bins + 1]; no holes
+        HIP_TRY(c, hipMemcpyAsync(L.counters, ps.bin_start + ps.bk.bins + 1, 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(L.counters + 1, 0, 4, c->stream));
+        L.cur = other;
+        rc = local_read(c);
+        if (rc) return rc;
+        L.n_sorted = L.n;
+        ps.binned = true;
+        ps.steps_since_sort = 0;
+        ps.sorts++;
+        ps.stray_pending = false;
+        ps.stray_steps = 0.0;
+        return FLUID_OK;
+    }
     const uint64_t n = c->particle_capacity, per_block = (uint64_t)PSORT_THREADS * PSORT_PER_THREAD;
     const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
     const float4* in = c->particles();
@@ -1143,13 +1221,13 @@ int psort_sort(fluid_ctx* c) {
     float4* out = dst ? ps.alt : c->particles_home();
     HIP_TRY(c, hipMemsetAsync(ps.bin_count, 0, ((uint64_t)ps.bk.bins + 2) * 4, c->stream));
     hipLaunchKernelGGL(k_pbin_histogram, dim3(blocks), dim3(PSORT_THREADS), 0, c->stream, in, n, c->g, c->pk,
-                       ps.bk, ps.bin_count);
+                       ps.bk, ps.bin_count, false);
     hipLaunchKernelGGL(k_pbin_scan, dim3(1), dim3(1024), 0, c->stream, ps.bin_count, ps.bk.bins + 1,
                        ps.bin_start, ps.cursor);
     const uint64_t per_block2 = (uint64_t)PSORT_THREADS * PSCATTER_PER_THREAD;
     hipLaunchKernelGGL(k_pbin_scatter, dim3((unsigned)((n + per_block2 - 1) / per_block2)), dim3(PSORT_THREADS), 0,
                        c->stream, in, slot_in, n, c->g,
-                       c->pk, ps.bk, ps.cursor, out, ps.slot_of[dst]);
+                       c->pk, ps.bk, ps.cursor, out, ps.slot_of[dst], false);
     HIP_TRY(c, hipGetLastError());
     ps.cur = dst;
     ps.valid = true;
@@ -1172,6 +1250,12 @@ int psort_sort(fluid_ctx* c) {
 // back to slot order in the arena's buffer (sorting switched off, or suspended)
 int psort_to_slot_order(fluid_ctx* c) {
     auto& ps = c->ps;
+    if (c->is_slab) {  // a slab's storage has no slot order to go back to: the bins are simply not used
+        ps.binned = false;
+        ps.stray_pending = false;
+        ps.stray_steps = 0.0;
+        return FLUID_OK;
+    }
     if (ps.valid) {
         hipLaunchKernelGGL(k_pbin_to_slot_order, dim3((unsigned)((c->particle_capacity + 255) / 256)),
                            dim3(256), 0, c->stream, c->particles(), ps.slot_of[ps.cur],
@@ -1195,7 +1279,7 @@ int psort_before_count(fluid_ctx* c) {
         return psort_to_slot_order(c);
     }
     if (ps.stray_pending && hipEventQuery(ps.stray_ev) == hipSuccess) {
-        ps.stray_steps += (double)ps.stray_host[1] / (double)c->particle_capacity;
+        ps.stray_steps += (double)ps.stray_host[1] / (double)std::max<uint64_t>(psort_n(c), 1);
         ps.stray_pending = false;
     }
     const int64_t mode = c->opt[FLUID_OPT_PARTICLE_SORT];
@@ -1205,7 +1289,7 @@ int psort_before_count(fluid_ctx* c) {
         return psort_sort(c);  // try again
     }
     const bool again = mode == 3 || (mode != 4 && ps.stray_steps >= 0.3);
-    if (ps.valid && ps.binned && again && mode != 3) {
+    if ((ps.valid || c->is_slab) && ps.binned && again && mode != 3) {
         // strays per step, from the triangle the fractions have summed to: sum = r T^2 / 2
         const double T = (double)ps.steps_since_sort;
         if (2.0 * ps.stray_steps / (T * T) > 0.03) {
@@ -1215,7 +1299,7 @@ int psort_before_count(fluid_ctx* c) {
         }
         if (T >= 32.0) ps.backoff = 64;  // a calm spell
     }
-    if (!ps.valid || !ps.binned || again) return psort_sort(c);
+    if ((!ps.valid && !c->is_slab) || !ps.binned || again) return psort_sort(c);
     return FLUID_OK;
 }
 // 01 on the sorted storage; `marks` = pbricks() or null
@@ -1231,6 +1315,14 @@ int psort_count(fluid_ctx* c, uint32_t* dens, uint8_t* marks, const BrickK& bk) 
                            ps.bin_start, ps.bk, dens, c->g, c->pk, marks, bk, ps.strays, ps.stray_count);
     hipLaunchKernelGGL(k01_binned_strays, dim3(1024), dim3(256), 0, c->stream, ps.strays, ps.stray_count, dens,
                        c->g, marks, bk);
+    if (c->is_slab && c->loc.n > c->loc.n_sorted) {
+        // what the slab has adopted since the sort sits behind the sorted entries, in no order: the slot-order
+        // kernel (it adds with atomics, after the plain stores of the bins in stream order)
+        const uint64_t per_block = (uint64_t)K01_THREADS * K01_PER_THREAD, n = c->loc.n - c->loc.n_sorted;
+        hipLaunchKernelGGL(k01_update_densities, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(K01_THREADS), 0,
+                           c->stream, c->particles() + c->loc.n_sorted, n, dens, c->g, c->pk, marks, bk,
+                           (const uint32_t*)nullptr);
+    }
     HIP_TRY(c, hipGetLastError());
     if (!ps.stray_pending) {
         HIP_TRY(c, hipMemcpyAsync(ps.stray_host, ps.stray_count, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1544,11 +1636,17 @@ int run_section_impl(fluid_ctx* c, int section) {
             if (c->ps.binned) {
                 // few full bins (a sparse scene): two workgroups share a bin, each staging its tile (512^3 dam
                 // break: 0.36 -> 0.26 ms; the full tank loses 8 % that way)
-                const uint32_t parts = c->particle_capacity / (8u * PBIN_CELLS) < 256 * 32 ? 2u : 1u;
+                const uint32_t parts = psort_n(c) / (8u * PBIN_CELLS) < 256 * 32 ? 2u : 1u;
                 const unsigned blocks =
                     (unsigned)std::min<uint64_t>(((uint64_t)c->ps.bk.bins + 1) * parts, 256 * 64);
                 hipLaunchKernelGGL(k14_binned, dim3(blocks), dim3(256), 0, c->stream, V1, c->particles(),
                                    c->ps.bin_start, c->ps.bk, g, pk, c->flags(), parts);
+                if (c->is_slab && c->loc.n > c->loc.n_sorted) {  // adopted since the sort: behind the bins, unordered
+                    const uint64_t n = c->loc.n - c->loc.n_sorted;
+                    hipLaunchKernelGGL(k14_particles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, V1,
+                                       c->particles() + c->loc.n_sorted, n, g, pk, c->flags(),
+                                       (const uint32_t*)nullptr);
+                }
             } else {
                 const uint64_t n = walk_entries(c);
                 if (n)
@@ -1966,7 +2064,8 @@ int fluid_upload_buffer(fluid_ctx* c, int buffer_id, const void* host, uint64_t 
             }
             auto& L = c->loc;
             L.on = true;
-            L.n = L.holes = 0;
+            L.n = L.holes = L.n_sorted = 0;
+            L.cur = 0;
             int rc2 = local_reserve(c, keep.size());
             if (rc2) return rc2;
             if (!keep.empty()) {
@@ -2019,8 +2118,8 @@ int fluid_download_buffer(fluid_ctx* c, int buffer_id, void* host, uint64_t byte
         if (n) {
             std::vector<float4> data(n);
             std::vector<uint32_t> ids(n);
-            HIP_TRY(c, hipMemcpyAsync(data.data(), c->loc.buf[0], (uint64_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(ids.data(), c->loc.pid[0], (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(data.data(), c->loc.buf[c->loc.cur], (uint64_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(ids.data(), c->loc.pid[c->loc.cur], (uint64_t)n * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (uint32_t k = 0; k < n; k++) {
                 uint32_t w;
@@ -3027,7 +3126,7 @@ int fluid_particles_collect(fluid_ctx* c, int reset_lists, uint32_t counts[2], u
     const uint32_t n = c->loc.on ? c->loc.n : 0u;
     if (n) {
         hipLaunchKernelGGL(k_particles_collect_leavers, dim3((n + 255) / 256), dim3(256), 0, c->stream,
-                           c->loc.buf[0], c->loc.pid[0], n, c->g, c->migrate_lists(), c->loc.counters);
+                           c->loc.buf[c->loc.cur], c->loc.pid[c->loc.cur], n, c->g, c->migrate_lists(), c->loc.counters);
         HIP_TRY(c, hipGetLastError());
     }
     int rc = read_migrate_counts(c, counts, left_behind);

@@ -41,10 +41,15 @@ struct PBinK {
 };
 
 // the bin a particle counts in: the cell of update_densities.comp:35 (ivec3 truncation; dropped outside)
+// the cell a particle counts towards, as this context addresses it (cz = LOCAL plane), or false: inactive,
+// outside the grid, a tombstone, or — Z-slab contexts — in a plane of another slab
 __device__ __forceinline__ bool particle_cell(const float4& q, const GridK& g, const ParamsK& p, int& cx,
                                               int& cy, int& cz) {
-    return q.w == p.active_w && trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) &&
-           trunc_index(q.z, g.Dg, cz);
+    if (!(q.w == p.active_w && trunc_index(q.x, g.W, cx) && trunc_index(q.y, g.H, cy) &&
+          trunc_index(q.z, g.Dg, cz)))
+        return false;
+    cz -= g.z0;
+    return (unsigned)cz < (unsigned)g.Dl;
 }
 __device__ __forceinline__ uint32_t particle_bin(const float4& q, const GridK& g, const ParamsK& p,
                                                  const PBinK& b) {
@@ -104,7 +109,7 @@ __device__ __forceinline__ WaveKey psort_wave_insert(uint32_t* keys, uint32_t ke
 // pass 1: particles per bin
 __global__ void __launch_bounds__(PSORT_THREADS)
 k_pbin_histogram(const float4* __restrict__ particles, uint64_t capacity, GridK g, ParamsK p, PBinK b,
-                 uint32_t* __restrict__ bin_count) {
+                 uint32_t* __restrict__ bin_count, bool drop_tombstones) {
     __shared__ uint32_t keys[PSORT_TABLE];
     __shared__ uint32_t counts[PSORT_TABLE];
     for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS) {
@@ -116,8 +121,10 @@ k_pbin_histogram(const float4* __restrict__ particles, uint64_t capacity, GridK 
 #pragma unroll 4
     for (int k = 0; k < PSORT_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
-        const bool in = i < capacity;
-        const uint32_t key = in ? particle_bin(particles[i], g, p, b) : 0u;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < capacity) q = particles[i];
+        const bool in = i < capacity && !(drop_tombstones && is_tombstone(q));  // (a slab's holes are dropped by the sort)
+        const uint32_t key = in ? particle_bin(q, g, p, b) : 0u;
         const WaveKey w = psort_wave_insert(keys, key, in);
         if (w.leader) {
             if (w.entry >= 0)
@@ -165,7 +172,7 @@ constexpr int PSCATTER_PER_THREAD = 8;
 __global__ void __launch_bounds__(PSORT_THREADS)
 k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict__ slot_in, uint64_t capacity,
                GridK g, ParamsK p, PBinK b, uint32_t* __restrict__ cursor, float4* __restrict__ out,
-               uint32_t* __restrict__ slot_out) {
+               uint32_t* __restrict__ slot_out, bool drop_tombstones) {
     __shared__ uint32_t keys[PSORT_TABLE];
     __shared__ uint32_t counts[PSORT_TABLE];  // particles of the block per entry, then the entry's base
     for (int i = threadIdx.x; i < PSORT_TABLE; i += PSORT_THREADS) {
@@ -180,8 +187,8 @@ k_pbin_scatter(const float4* __restrict__ particles, const uint32_t* __restrict_
 #pragma unroll
     for (int k = 0; k < PSCATTER_PER_THREAD; k++) {
         const uint64_t i = base + (uint64_t)k * PSORT_THREADS + threadIdx.x;
-        const bool in = i < capacity;
-        q[k] = in ? particles[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[k] = i < capacity ? particles[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in = i < capacity && !(drop_tombstones && is_tombstone(q[k]));
         const uint32_t key = in ? particle_bin(q[k], g, p, b) : 0u;
         const WaveKey w = psort_wave_insert(keys, key, in);
         // one reservation per wavefront and key: the leader's old count is where its lanes start
@@ -382,6 +389,9 @@ __device__ __forceinline__ bool tile_velocity(const BinTile& t, const GridK& g, 
           (unsigned)(y0[1] - yo) < (unsigned)PTILE_H && (unsigned)(y1[0] - yo) < (unsigned)PTILE_H &&
           (unsigned)(z0[1] - zo) < (unsigned)PTILE_D && (unsigned)(z1[0] - zo) < (unsigned)PTILE_D))
         return false;
+    // a Z slab: a tap beyond the ghost planes that hold the neighbouring slab's current data is the global
+    // sampler's business (it raises the halo-violation flag)
+    if (z0[1] - g.z0 < -g.sg_lo || z1[0] - g.z0 >= g.Dl + g.sg_hi) return false;
     // component `c`, staggered on the axes whose s* flag is 0 ([0] = staggered taps)
     auto tri = [&](const FLUID_LDS_F float* c, int sx, int sy, int sz) {
         const int r00 = PTILE_W * ((y0[sy] - yo) + PTILE_H * (z0[sz] - zo)) - xo;
@@ -445,7 +455,8 @@ k14_binned(const float4* __restrict__ v1, float4* __restrict__ particles,
         for (int c = threadIdx.x; c < PTILE_CELLS; c += 256) {
             const int x = t.x_org + c % PTILE_W, y = t.y_org + (c / PTILE_W) % PTILE_H,
                       z = t.z_org + c / (PTILE_W * PTILE_H);
-            if ((unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H && (unsigned)z < (unsigned)g.Dl) {
+            // (local planes; a slab's ghost planes are loaded too — whether a tap may use them is tile_velocity's test)
+            if ((unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H && z >= -IMG_GHOST && z < g.Dl + IMG_GHOST) {
                 const float4 v = v1[cidx(g, x, y, z)];
                 tile[0][c] = v.x;
                 tile[1][c] = v.y;
