@@ -557,8 +557,11 @@ typedef enum fluid_option {
                                    /* slots (default; needs 28 B per slot outside the arena, falls back to slot */
                                    /* order if that cannot be allocated), 1 = off, 2 = on at any size; 3 / 4 =   */
                                    /* test modes (sort before every 01 / sort once and never again).            */
-                                   /* Z-slab contexts store the particles they own compactly, in no particular  */
-                                   /* order, whatever the value (3: holes are squeezed out at once; tests)      */
+                                   /* Z-slab contexts store the particles they OWN compactly (20 B per entry)   */
+                                   /* and sort that storage by the bins of their own planes under the same      */
+                                   /* values (0 = from 4 M entries; a second set of arrays while sorting is on); */
+                                   /* a sort drops the holes leavers left, adopted particles sit behind the     */
+                                   /* bins until the next sort                                                  */
     FLUID_OPT_COUNT
 } fluid_option;
 int fluid_set_option(fluid_ctx* ctx, int option, int64_t value);
@@ -603,7 +606,8 @@ typedef enum fluid_stat {
     FLUID_STAT_PARTICLE_ENTRIES = 5, /* Z-slab contexts: entries (holes included) of the compact storage of the   */
                                      /* particles the slab owns, which 01, 14 and the search for leavers walk;  */
                                      /* whole-grid contexts: the number of slots                                */
-    FLUID_STAT_OWNED_SQUEEZES = 6    /* times that storage had its holes squeezed out                       */
+    FLUID_STAT_OWNED_SQUEEZES = 6    /* times that storage had its holes squeezed out (sorts, which drop    */
+                                     /* the holes too, are counted by FLUID_STAT_PARTICLE_SORTS)            */
 } fluid_stat;
 int fluid_get_stat(fluid_ctx* ctx, int stat, uint64_t* value);
 

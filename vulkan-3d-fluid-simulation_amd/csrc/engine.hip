@@ -666,9 +666,13 @@ int ensure_prepared(fluid_ctx* c, bool mask_only = false) {
         HIP_TRY(c, hipMemsetAsync(c->flags() + 10, 0, 8, c->stream));  // x extent of the water
     }
     // fast_loop_possible() guarantees W % 4 == 0: four cells per thread
+    GridK gb = c->g_bricks();
+    // (the mask pass of a step runs between 06 and the streak update, when neither skipping flag is up: one
+    // workgroup per brick layer all the same — 131 072 workgroups that test and leave cost 120 us at 512^3)
+    if (rebuilt_mask && unchanged && c->active_bytes >= 4096) gb.zl = BRICK_Z;
     k12_launch_prepare_v4(c->stream, c->plane0<uint8_t>(FLUID_IMG_CELL_TYPES),
                           c->plane0<float>(FLUID_IMG_DIVERGENCES), c->mask0(), c->rhs0(),
-                          c->bricks(), c->g_bricks(), c->pk, rebuilt_mask, want_rhs,
+                          c->bricks(), gb, c->pk, rebuilt_mask, want_rhs,
                           rebuilt_mask ? unchanged : c->quiet_or_null(), c->flags() + 10);
     HIP_TRY(c, hipGetLastError());
     c->mask_valid = true;
@@ -1501,6 +1505,19 @@ int run_section_impl(fluid_ctx* c, int section) {
             c->touched(FLUID_IMG_CELL_TYPES);
             // one ghost plane per side rides along: on a slab it holds the neighbour's new types
             // (exchanged after 03), at a domain face it is zero in both images
+            if (c->early_step && g.W % 4 == 0 && c->active_bytes >= 4096) {
+                // bricks that 02 and 03 skipped hold the same types in both images: copy the others
+                GridK ge = g;
+                ge.zl = BRICK_Z;
+                hipLaunchKernelGGL(k06_copy_types_v4, dim3((g.W / 4 + 63) / 64, grid.y, (g.Dl + BRICK_Z - 1) / BRICK_Z),
+                                   block, 0, c->stream, newT, T, ge, c->early(), bk);
+                if (g.z0 > 0)
+                    HIP_TRY(c, hipMemcpyAsync(T - g.plane, newT - g.plane, g.plane, hipMemcpyDeviceToDevice, c->stream));
+                if (g.z0 + g.Dl < g.Dg)
+                    HIP_TRY(c, hipMemcpyAsync(T + c->owned_cells(), newT + c->owned_cells(), g.plane,
+                                              hipMemcpyDeviceToDevice, c->stream));
+                break;
+            }
             HIP_TRY(c, hipMemcpyAsync(T - g.plane, newT - g.plane, c->owned_cells() + 2 * g.plane,
                                       hipMemcpyDeviceToDevice, c->stream));
             return FLUID_OK;
@@ -2554,7 +2571,7 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
     const bool early = c->driver_step ? c->ds_early
                                       : (quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid &&
                                          first == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES);
-    if (!c->driver_step) c->quiet_in_use = c->early_in_use = false;  // else they carry over between calls
+    if (!c->driver_step) c->quiet_in_use = c->early_in_use = c->early_step = false;  // else they carry over between calls
     for (int s = first; s < end;) {
         int rc, used = 1;
         if (early && s == FLUID_SEC_01A_CLEAR_PARTICLE_DENSITIES) {
@@ -2610,13 +2627,13 @@ static int run_step_slice(fluid_ctx* c, int first, int count, bool grouped, bool
             rc = timed_section(c, s);
         }
         if (rc) {
-            c->quiet_in_use = c->early_in_use = false;
+            c->quiet_in_use = c->early_in_use = c->early_step = false;
             return rc;
         }
         if (s == FLUID_SEC_13_FIX_DIVERGENCE) c->quiet_in_use = false;
         s += used;
     }
-    if (!c->driver_step) c->quiet_in_use = c->early_in_use = false;
+    if (!c->driver_step) c->quiet_in_use = c->early_in_use = c->early_step = false;
     return FLUID_OK;
 }
 
@@ -2666,7 +2683,7 @@ int fluid_step_begin(fluid_ctx* c, int section_list) {
                   fast_loop_possible(c) &&
                   c->diffuse_mode == FLUID_DIFFUSE_REFERENCE_EXACT && c->opt[FLUID_OPT_QUIET_BRICKS] != 1;
     c->ds_early = c->ds_quiet && c->quiet_valid && c->mask_valid && c->pbricks_valid;
-    c->quiet_in_use = c->early_in_use = false;
+    c->quiet_in_use = c->early_in_use = c->early_step = false;
     c->ghost_bricks_valid = false;
     c->box_from_driver = false;
     return FLUID_OK;
@@ -2675,7 +2692,7 @@ int fluid_step_begin(fluid_ctx* c, int section_list) {
 int fluid_step_end(fluid_ctx* c) {
     if (!c) return FLUID_ERR_INVALID_ARG;
     c->driver_step = false;
-    c->quiet_in_use = c->early_in_use = false;
+    c->quiet_in_use = c->early_in_use = c->early_step = false;
     return FLUID_OK;
 }
 

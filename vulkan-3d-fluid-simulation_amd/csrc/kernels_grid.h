@@ -111,6 +111,18 @@ __global__ void k02_update_water_v4(const uint32_t* __restrict__ dens, uint8_t* 
     FLUID_CELL4_END
 }
 
+// 06_update_cell_types while bricks are being skipped: NEW_CELL_TYPES -> CELL_TYPES outside the bricks that 02 and
+// 03 left alone (there both images hold the previous step's types already; fluid_flow_sections.h:236-241 copies
+// the whole image)
+__global__ void k06_copy_types_v4(const uint8_t* __restrict__ newT, uint8_t* __restrict__ t, GridK g,
+                                  const uint8_t* __restrict__ quiet, BrickK bk) {
+    FLUID_LEAVE_IF_QUIET_V4(quiet, bk)
+    FLUID_CELL4_THREAD();
+    (void)gz;
+    *reinterpret_cast<uint32_t*>(t + id) = *reinterpret_cast<const uint32_t*>(newT + id);
+    FLUID_CELL4_END
+}
+
 __global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p,
                                   const uint8_t* __restrict__ quiet, BrickK bk) {
     FLUID_LEAVE_IF_QUIET_V4(quiet, bk)

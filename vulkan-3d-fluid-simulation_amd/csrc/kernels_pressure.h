@@ -289,18 +289,30 @@ __global__ void k12_count_bricks(const uint8_t* __restrict__ active, BrickK bk,
     __syncthreads();
     const int n = bk.nbx * bk.nby * bk.nbz;
     uint32_t c = 0, ylo = 0xFFFFFFFFu, yhi = 0, zlo = 0xFFFFFFFFu, zhi = 0, xlo = 0xFFFFFFFFu, xhi = 0;
-    for (int i = threadIdx.x; i < n; i += 256)
-        if (active[i]) {
-            const uint32_t by = (uint32_t)((i / bk.nbx) % bk.nby), bz = (uint32_t)(i / (bk.nbx * bk.nby));
-            const uint32_t bx = (uint32_t)(i % bk.nbx);
-            c++;
-            xlo = min(xlo, bx);
-            xhi = max(xhi, bx + 1u);
-            ylo = min(ylo, by);
-            yhi = max(yhi, by + 1u);
-            zlo = min(zlo, bz);
-            zhi = max(zhi, bz + 1u);
+    // eight loads in flight per thread (a loop of dependent single-byte loads took 26 us for 8192 bricks)
+    for (int base = 0; base < n; base += 256 * 8) {
+        uint8_t a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            const uint8_t v = active[min(i, n - 1)];  // (unconditional: a guarded load waits for the one before)
+            a[k] = i < n ? v : (uint8_t)0;
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (a[k]) {
+                const int i = base + k * 256 + (int)threadIdx.x;
+                const uint32_t by = (uint32_t)((i / bk.nbx) % bk.nby), bz = (uint32_t)(i / (bk.nbx * bk.nby));
+                const uint32_t bx = (uint32_t)(i % bk.nbx);
+                c++;
+                xlo = min(xlo, bx);
+                xhi = max(xhi, bx + 1u);
+                ylo = min(ylo, by);
+                yhi = max(yhi, by + 1u);
+                zlo = min(zlo, bz);
+                zhi = max(zhi, bz + 1u);
+            }
+    }
     if (c) {
         atomicAdd(&sh[0], c);
         atomicMin(&sh[1], ylo);
