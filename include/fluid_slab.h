@@ -203,6 +203,7 @@ typedef enum fluid_slab_stat {
     FLUID_SLAB_STAT_SAMPLER_HALO = 6,     /* ghost planes of VELOCITIES_1 currently exchanged for 07      */
     FLUID_SLAB_STAT_MIGRATE_ROUNDS = 7,   /* hand-over rounds that moved particles                        */
     FLUID_SLAB_STAT_RCCL_RANKS = 8,       /* ncclCommCount of the attached communicator (0: no RCCL)      */
+    FLUID_SLAB_STAT_DRY_FACE_SKIPS = 9,   /* loop exchanges left out at a face with no water near it      */
     FLUID_SLAB_STAT_COUNT
 } fluid_slab_stat;
 int fluid_slab_get_stat(fluid_slab* s, int stat, uint64_t* value);

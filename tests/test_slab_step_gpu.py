@@ -21,17 +21,19 @@ def _free_port():
     return port
 
 
-def scene_params(size, intended=False):
-    """Dam-break block placed across the slab faces: 8 particles per cell, z from 25 % to 75 %.
+def scene_params(size, intended=False, zspan=None):
+    """Dam-break block placed across the slab faces: 8 particles per cell, z from 25 % to 75 %
+    (zspan = (first, extent) as fractions of the depth puts it elsewhere).
     intended: a diffusion coefficient for 09_diffuse in FLUID_DIFFUSE_INTENDED mode."""
     import fluid_amd
     w, h, d = size
     p, _ = fluid_amd.dam_break_params(w, h, d)
-    ext = (0.5 * w, 0.5 * h, 0.5 * d)
+    z_first, z_ext = zspan if zspan else (0.25, 0.5)
+    ext = (0.5 * w, 0.5 * h, z_ext * d)
     res = tuple(max(1, int(round(2 * e))) for e in ext)
     p.particle_spawn_cube_resolution[:] = res
     p.particle_spawn_cube_volume = res[0] * res[1] * res[2]
-    p.particle_spawn_cube_offset[:] = (0.25 * w, 0.15 * h, 0.25 * d)
+    p.particle_spawn_cube_offset[:] = (0.25 * w, 0.15 * h, z_first * d)
     p.particle_spawn_cube_size[:] = ext
     cap = res[0] * res[1] * res[2] + 37  # a few inactive slots at the end
     p.particle_compute_size[:] = (cap, 1)
@@ -50,7 +52,8 @@ def drift(shape, fast=0.0):
     return v
 
 
-def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0, plain_slots=False):
+def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=False, fast=0.0, plain_slots=False,
+            zspan=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -65,7 +68,7 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     from test_slab_step_gpu import drift, scene_params
 
     dist.init_process_group(backend="gloo")
-    params, cap = scene_params(size, intended)
+    params, cap = scene_params(size, intended, zspan)
     # the product's C++ driver on the HIP engine; only the wire differs from an N-GPU run: the ranks
     # share GPU 0, where RCCL refuses to run, so the planes are staged through the host over gloo
     sim = S.SlabDriver(params, rank, world, particle_capacity=cap, pressure_iterations=iters, device=0,
@@ -92,7 +95,8 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     t = torch.tensor([sim.stat(i) for i in range(8)] + [sim.engine.get_stat(E.STAT_QUIET_BRICKS),
                                                         sim.engine.get_stat(E.STAT_PARTICLE_ENTRIES),
                                                         sim.engine.get_stat(E.STAT_OWNED_SQUEEZES),
-                                                        sim.engine.get_stat(E.STAT_PARTICLE_SORTS)],
+                                                        sim.engine.get_stat(E.STAT_PARTICLE_SORTS),
+                                                        sim.stat(S.STAT_DRY_FACE_SKIPS)],
                      dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -102,11 +106,11 @@ def _worker(rank, world, port, size, iters, steps, grouped, out_dir, intended=Fa
     dist.destroy_process_group()
 
 
-def _check(got, world, size, iters, steps, intended=False, fast=0.0):
+def _check(got, world, size, iters, steps, intended=False, fast=0.0, zspan=None):
     from helpers import assert_bit_equal
     from oracle_binding import OracleState
 
-    params, cap = scene_params(size, intended)
+    params, cap = scene_params(size, intended, zspan)
     st = OracleState(params, cap, iters, diffuse_mode=1 if intended else 0)
     st.run_init()
     st.run_step()
@@ -158,6 +162,31 @@ def test_slab_simulation_matches_oracle(world, size, iters, steps, grouped, inte
     assert np.any(st.cell_types[face - 1] == 2) and np.any(st.cell_types[face] == 2)
     assert int(got["stats"][S.STAT_MIGRATED]) > 0
     assert int(got["stats"][S.STAT_SAMPLER_RERUNS]) == 0
+
+
+@pytest.mark.parametrize("world,steps", [(2, 8), (2, 40), (3, 40)])
+def test_slab_loop_leaves_dry_faces_out(world, steps, tmp_path):
+    """A block of water well inside the lowest slab, drifting towards the face: while no water lies within eight
+    planes of a face on either side, the Jacobi loop exchanges nothing there (the planes it would move hold the
+    constants of non-water cells, primed once per loop in all three working buffers) — the step's table of boxes
+    tells both ranks of a face the same thing; when the water comes near, the exchanges are back.  Bit-identical
+    to the oracle throughout."""
+    import torch.multiprocessing as mp
+
+    from fluid_amd import slab as S
+
+    size, iters, zspan = (32, 24, 64 * world), 12, (0.05 * 2 / world, 0.30 * 2 / world)   # z 6.4 .. 44.8
+    mp.start_processes(_worker, args=(world, _free_port(), size, iters, steps, True, str(tmp_path), False, 0.0, False,
+                                      zspan),
+                       nprocs=world, join=True, start_method="spawn")
+    got = np.load(os.path.join(str(tmp_path), "result.npz"))
+    st = _check(got, world, size, iters, steps, zspan=zspan)
+    skips, exchanges = int(got["stats"][12]), int(got["stats"][S.STAT_EXCHANGES])
+    assert skips > 0, (skips, exchanges)
+    print("dry-face skips", skips, "exchanges", exchanges, "water in the last layer of slab 0:",
+          bool(np.any(st.cell_types[48:64] == 2)))
+    if steps >= 40:   # the water has reached the last brick layer of the lowest slab: its upper face is wet again
+        assert np.any(st.cell_types[48:64] == 2)
 
 
 @pytest.mark.parametrize("world,size", [(2, (64, 64, 96)), (3, (256, 48, 96))])

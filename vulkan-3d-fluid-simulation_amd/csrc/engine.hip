@@ -2745,6 +2745,9 @@ int fluid_step_status(fluid_ctx* c, uint32_t words[8]) {
         words[6] = std::min<uint32_t>(h[6], (uint32_t)c->g.W);
         c->box.z_lo = (int)h[3] * bz;                             // local planes: this context's own
         c->box.z_hi = std::min((int)h[4] * bz, c->g.Dl);
+        // ... and for the driver: which owned planes hold water, [lo, hi) in the two halves of the word (the
+        // slab driver leaves the loop's exchanges out at a face no water is near on either side)
+        words[7] = ((uint32_t)c->box.z_lo & 0xFFFFu) | ((uint32_t)std::min(c->box.z_hi, 0xFFFF) << 16);
         c->box.fraction = (float)h[0] / (float)c->active_bytes;
     }
     return FLUID_OK;

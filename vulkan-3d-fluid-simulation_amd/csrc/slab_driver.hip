@@ -428,6 +428,10 @@ struct fluid_slab {
     std::unique_ptr<Backend> be;
     std::unique_ptr<Transport> tr;
     bool loopback = false;
+    // faces (0 lower, 1 upper) with no water within FLUID_LOOP_MAX_HALO planes on either side, from the step's
+    // table of boxes: the Jacobi loop's exchanges there would move planes that do not change
+    bool dry_face[2] = {false, false};
+    bool dry_valid = false;  // set by the step's table, used up by the loop that follows
     uint64_t stats[FLUID_SLAB_STAT_COUNT] = {0};
     std::string error;
 
@@ -476,8 +480,9 @@ enum PlanKind { PLAN_IMAGE = 0, PLAN_LOOP = 1 };
 
 // Boundary-plane exchange with the two Z-neighbours: send the first / last `width` owned planes down /
 // up, receive their last / first owned planes into the ghost planes.  Pointers never move: built once.
-int get_plan(fluid_slab* s, int kind, int id, uint32_t width, const std::vector<Xfer>** out) {
-    const auto key = std::make_tuple(kind, id, width);
+// `skip`: bit 0 / 1 = leave the lower / upper face out (solve(): dry faces)
+int get_plan(fluid_slab* s, int kind, int id, uint32_t width, const std::vector<Xfer>** out, uint32_t skip = 0) {
+    const auto key = std::make_tuple(kind, id, width | (skip << 24));
     auto it = s->plans.find(key);
     if (it == s->plans.end()) {
         if (s->dl < width)
@@ -495,11 +500,11 @@ int get_plan(fluid_slab* s, int kind, int id, uint32_t width, const std::vector<
             return FLUID_OK;
         };
         const int32_t n = (int32_t)s->dl, w = (int32_t)width;
-        if (s->lo >= 0) {
+        if (s->lo >= 0 && !(skip & 1u)) {
             TRY(add(0, s->lo, true));
             TRY(add(-w, s->lo, false));
         }
-        if (s->hi >= 0) {
+        if (s->hi >= 0 && !(skip & 2u)) {
             TRY(add(n - w, s->hi, true));
             TRY(add(n, s->hi, false));
         }
@@ -557,10 +562,10 @@ int exchange_image(fluid_slab* s, int image, uint32_t width) {
     BE(ghost_written(image));
     return FLUID_OK;
 }
-int exchange_loop(fluid_slab* s, int buf, uint32_t width) {
+int exchange_loop(fluid_slab* s, int buf, uint32_t width, uint32_t skip = 0) {
     if (!s->has_peers() || width == 0) return FLUID_OK;
     const std::vector<Xfer>* plan = nullptr;
-    TRY(get_plan(s, PLAN_LOOP, buf, width, &plan));
+    TRY(get_plan(s, PLAN_LOOP, buf, width, &plan, skip));
     return exchange_now(s, *plan);
 }
 
@@ -621,6 +626,17 @@ int solve(fluid_slab* s, uint32_t n) {
     uint32_t nbufs = 0;
     BE(loop_begin(h, bufs, &nbufs));
     for (uint32_t i = 0; i < nbufs; i++) TRY(exchange_loop(s, bufs[i].which, bufs[i].planes));
+    // Dry faces (advect(): no water within the deepest halo on either side, this step): the planes the loop
+    // would exchange there hold the constants of their non-water cells from the first sweep to the last, in all
+    // three working buffers — they get them once, here, and the exchanges of the loop leave those faces out
+    // (the launches still recompute the ghost region: the same constants).  Only with the engine's working
+    // buffers (three of them, numbered 0 .. 2, constants laid down by the import pass).
+    uint32_t dry = 0;
+    if (max_sweeps >= 2 && nbufs == 3 && s->has_peers() && s->tr && s->dry_valid)
+        dry = (s->dry_face[0] ? 1u : 0u) | (s->dry_face[1] ? 2u : 0u);
+    s->dry_valid = false;  // (of one step's cell types: the next loop needs a new table)
+    if (dry)
+        for (int b = 1; b <= 2; b++) TRY(exchange_loop(s, b, h, 3u & ~dry));
     BE(loop_halo_exchanged(h, true));
     int32_t valid = (int32_t)h;  // valid ghost planes of the newest iterate
     int cur = 0;                 // buffer holding it
@@ -638,7 +654,8 @@ int solve(fluid_slab* s, uint32_t n) {
         const uint32_t sweeps = now.sweeps;
         const bool keep = sweeps >= 2 && n - k == sweeps;
         if (now.exchange) {
-            TRY(exchange_loop(s, cur, h));
+            if (dry) s->stats[FLUID_SLAB_STAT_DRY_FACE_SKIPS] += (dry & 1u) + ((dry >> 1) & 1u);
+            TRY(exchange_loop(s, cur, h, dry));
             BE(loop_halo_exchanged(h, false));
             valid = hh;
         }
@@ -664,7 +681,8 @@ int solve(fluid_slab* s, uint32_t n) {
             int dst = 0;
             BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_EDGES, before_lo, before_hi, &dst));
             const std::vector<Xfer>* plan = nullptr;
-            TRY(get_plan(s, PLAN_LOOP, dst, h, &plan));
+            TRY(get_plan(s, PLAN_LOOP, dst, h, &plan, dry));
+            if (dry) s->stats[FLUID_SLAB_STAT_DRY_FACE_SKIPS] += (dry & 1u) + ((dry >> 1) & 1u);
             TRY(exchange_start(s, *plan));
             in_flight = true;
             BE(loop_advance(k, sweeps, keep, FLUID_LOOP_PART_INTERIOR, before_lo, before_hi, &cur));
@@ -773,7 +791,7 @@ int advect(fluid_slab* s) {
     uint32_t w[8];
     BE(step_status(w));
     uint32_t flag = w[0];
-    constexpr uint32_t K = 7;  // words per rank: flag, box known, bricks, ~y_lo, y_hi, ~x_lo, x_hi
+    constexpr uint32_t K = 8;  // words per rank: flag, box known, bricks, ~y_lo, y_hi, ~x_lo, x_hi, z range
     std::vector<uint32_t> table((size_t)K * s->world, 0u);
     uint32_t* mine = table.data() + (size_t)K * s->rank;
     mine[0] = flag;
@@ -783,7 +801,31 @@ int advect(fluid_slab* s) {
     mine[4] = w[4];
     mine[5] = ~w[5];
     mine[6] = w[6];
+    mine[7] = w[7];
     TRY(reduce_max(s, table.data(), (uint32_t)table.size()));
+    {
+        // a face is dry when neither slab at it has water within the deepest halo of the loop: the planes an
+        // exchange would move there hold constants (non-water cells are never written, pressure.comp:69)
+        auto near = [&](int q, bool upper_face_of_q) {
+            const uint32_t* t = table.data() + (size_t)K * q;
+            if (t[1] == 0) return true;   // box not known: assume water
+            if (t[2] == 0) return false;  // no water in that slab
+            uint32_t qz0, qn;
+            slab_of(s->D, s->world, (uint32_t)q, &qz0, &qn);
+            const uint32_t zlo = t[7] & 0xFFFFu, zhi = t[7] >> 16;
+            return upper_face_of_q ? zhi + FLUID_LOOP_MAX_HALO > qn : zlo < FLUID_LOOP_MAX_HALO;
+        };
+        const int me = (int)s->rank;
+        if (s->loopback) {  // the neighbour is this slab's mirror image
+            const bool wet = near(me, false) || near(me, true);
+            s->dry_face[0] = s->lo >= 0 && !wet;
+            s->dry_face[1] = s->hi >= 0 && !wet;
+        } else {
+            s->dry_face[0] = s->lo >= 0 && !near(me, false) && !near(s->lo, true);
+            s->dry_face[1] = s->hi >= 0 && !near(me, true) && !near(s->hi, false);
+        }
+        s->dry_valid = true;
+    }
     {
         bool known = true;
         uint32_t y0 = ~0u, y1 = 0, x0 = ~0u, x1 = 0;

@@ -28,7 +28,7 @@ from .params import PARAMS_BYTES, FluidParams, default_params
 OVERLAP_NONE, OVERLAP_BEFORE, OVERLAP_BOTH = 0, 1, 2
 OPT_OVERLAP, OPT_HALO_DEPTH, OPT_SAMPLER_HALO = 0, 1, 2
 (STAT_EXCHANGES, STAT_OVERLAPPED, STAT_MIGRATED, STAT_SAMPLER_RERUNS, STAT_SAMPLER_WIDE,
- STAT_EFFECTIVE_HALO, STAT_SAMPLER_HALO, STAT_MIGRATE_ROUNDS, STAT_RCCL_RANKS) = range(9)
+ STAT_EFFECTIVE_HALO, STAT_SAMPLER_HALO, STAT_MIGRATE_ROUNDS, STAT_RCCL_RANKS, STAT_DRY_FACE_SKIPS) = range(10)
 XFER_SEND, XFER_HOST_MEMORY = 1, 2
 RCCL_ID_BYTES = 128
 LOOP_PART_EDGES, LOOP_PART_INTERIOR = 1, 2
