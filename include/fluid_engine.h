@@ -460,7 +460,8 @@ int fluid_particles_adopt_received(fluid_ctx* ctx, uint32_t from_below, uint32_t
  *                               exchange the bricks at a shared face are never skipped.
  *   fluid_step_status           after 07 (+ 08): words[0] = the halo-violation flag (read and cleared, as
  *                               fluid_slab_status), words[1] = 1 if the box of this context's water is known,
- *                               then [2] = bricks with water, rows [3], [4)), cells [5], [6)) along x.
+ *                               then [2] = bricks with water, rows [3], [4)), cells [5], [6)) along x,
+ *                               [7] = the owned planes with water, first | (end << 16), in brick layers of 16.
  *                               Synchronises the stream once (the reduction the sampler protocol needs anyway).
  *   fluid_step_set_box          the launches of the pressure loop cover only these rows and — where the water
  *                               spans at most two 256-cell columns — this x window: the UNION of this context's
