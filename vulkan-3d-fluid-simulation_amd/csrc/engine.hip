@@ -1497,10 +1497,16 @@ int run_section_impl(fluid_ctx* c, int section) {
         case STEP_091011_SOLIDS_DIVERGENCE:
             c->touched(FLUID_IMG_DIVERGENCES);
             c->v1_w_zero = false;
+        {
+            // the loop's b_i rides along when the working-buffer loop will run on it (the same bricks are skipped
+            // by this pass and by the b_i pass: where DIVERGENCES does not change, b_i does not either)
+            float* rhs = fast_loop_possible(c) && c->solver != FLUID_SOLVER_RED_BLACK_SOR ? c->rhs0() : nullptr;
             hipLaunchKernelGGL(k091011_solids_divergence, qgrid, block, 0, c->stream, T, V2, V1,
                                c->plane0<float>(FLUID_IMG_DIVERGENCES), gqh, pk, c->quiet_or_null(), bk,
-                               qchunks);
+                               qchunks, rhs);
+            if (rhs) c->rhs_valid = true;
             break;
+        }
         case FLUID_SEC_06_UPDATE_CELL_TYPES:
             c->touched(FLUID_IMG_CELL_TYPES);
             // one ghost plane per side rides along: on a slab it holds the neighbour's new types

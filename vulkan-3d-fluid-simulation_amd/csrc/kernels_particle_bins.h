@@ -358,23 +358,20 @@ __device__ __forceinline__ pk2 lerp2(pk2 A, pk2 B, pk2 a) { return ((pk2)(1.0f) 
 // axis_taps for coord + 0.5f (.x) and coord + 0.0f (.y) at once
 __device__ __forceinline__ void axis_taps2(float coord, const AxisN& ax, int (&i0)[2], int (&i1)[2], pk2& a) {
     const pk2 c = (pk2)(coord) + (pk2){0.5f, 0.0f};
-    pk2 s;
-    if (ax.pow2)
-        s = c * (pk2)(ax.inv);
-    else
-        s = (pk2){c.x / ax.fn, c.y / ax.fn};
-    const pk2 u = s * (pk2)(ax.fn);
+    pk2 u = c;  // a power of two: c / n * n gives c back where it matters (axis_taps)
+    if (!ax.pow2) {
+        const pk2 s = (pk2){c.x / ax.fn, c.y / ax.fn};
+        u = s * (pk2)(ax.fn);
+    }
     const pk2 ub = u - (pk2)(0.5f);
     pk2 fl = (pk2){floorf(ub.x), floorf(ub.y)};
     a = ub - fl;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        float f = k == 0 ? fl.x : fl.y;
-        if (!(f >= -1.0f)) f = -1.0f;  // also catches NaN
-        if (f > ax.fn) f = ax.fn;
-        const int lo = (int)f, hi = lo + 1;
-        i0[k] = min(max(lo, 0), ax.n - 1);
-        i1[k] = min(max(hi, 0), ax.n - 1);
+        const float f = __builtin_amdgcn_fmed3f(k == 0 ? fl.x : fl.y, -1.0f, ax.fn);  // NaN -> -1 (axis_taps)
+        const int lo = (int)f;
+        i0[k] = clamp_index(lo, ax.n - 1);
+        i1[k] = min(lo + 1, ax.n - 1);
     }
 }
 __device__ __forceinline__ bool tile_velocity(const BinTile& t, const GridK& g, const Axes& axes, float px,

@@ -39,30 +39,34 @@ __device__ __forceinline__ Axes make_axes(const GridK& g) {
     a.z = make_axis(g.Dg);
     return a;
 }
+// clamp of a tap index: v_med3_i32 (hipcc does not form it from min(max()) with a bound it cannot order)
+__device__ __forceinline__ int clamp_index(int i, int last) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(last));
+    return r;
+}
 __device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0, int& i1, float& a) {
     const int n = ax.n;
     const float fn = ax.fn;
-    // coord / n.  For n a power of two the quotient is coord * 2^-k, exactly the same correctly rounded
-    // value (one rounding of the same real number, subnormal results included), without the ~11
-    // instructions of an IEEE division; 12 samples x 3 axes per advected cell make that worth a
-    // wave-uniform branch.
-    float s;
-    if (ax.pow2)
-        s = coord * ax.inv;
-    else
-        s = coord / fn;
-    const float u = s * fn;
+    // u = coord / n * n.  For n a power of two the quotient is coord * 2^-k, exactly, and the product gives
+    // coord back — unless the quotient is subnormal and loses bits, but then |coord| < 2^-100 and ub below is
+    // -0.5 with either value of u; zeros, infinities and NaN go through unchanged as well.  So u = coord: no
+    // division (~11 instructions of an IEEE sequence), no multiplication; 12 samples x 3 axes per advected
+    // cell make that worth a wave-uniform branch.
+    float u = coord;
+    if (!ax.pow2) {
+        const float s = coord / fn;
+        u = s * fn;
+    }
     const float ub = u - 0.5f;
     float fl = floorf(ub);
     a = ub - fl;
-    if (!(fl >= -1.0f)) fl = -1.0f;  // also catches NaN
-    if (fl > fn) fl = fn;
-    int lo = (int)fl;
-    int hi = lo + 1;
-    lo = min(max(lo, 0), n - 1);
-    hi = min(max(hi, 0), n - 1);
-    i0 = lo;
-    i1 = hi;
+    // fl into [-1, n]: v_med3_f32 returns the minimum of its operands when one is NaN, i.e. -1, which is what
+    // "if (!(fl >= -1)) fl = -1; if (fl > fn) fl = fn" makes of a NaN too
+    fl = __builtin_amdgcn_fmed3f(fl, -1.0f, fn);
+    const int lo = (int)fl;
+    i0 = clamp_index(lo, n - 1);
+    i1 = min(lo + 1, n - 1);  // lo + 1 >= 0 already
 }
 __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f - a) * A + a * B; }
 
