@@ -233,7 +233,7 @@ __global__ void k_pbin_to_slot_order(const float4* __restrict__ sorted, const ui
 // it holds has to stay, update_densities.comp:35 adds).  Strays (and the whole last segment, whose
 // particles counted nowhere when they were sorted): cell index appended to `strays`, added by
 // k01_binned_strays behind this kernel.  stray_count[0] = entries, [1] = particles found outside their bin.
-constexpr int K01_STRAY_BUF = 1024;  // stray keys a workgroup collects in LDS before it reserves list space
+constexpr int K01_STRAY_BUF = 1024;  // stray keys a workgroup collects in LDS per bin before it reserves list space
 template <bool ADD>
 __global__ void __launch_bounds__(256)
 k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bin_start, PBinK b,
@@ -249,7 +249,7 @@ k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bi
     // scene full of strays would otherwise queue up on.  Called by all threads.
     auto flush = [&](bool real) {
         __syncthreads();
-        const uint32_t n = sn;
+        const uint32_t n = min(sn, (uint32_t)K01_STRAY_BUF);  // (what did not fit went to the list directly)
         if (n) {
             if (threadIdx.x == 0) {
                 sbase = atomicAdd(&stray_count[0], n);
@@ -271,25 +271,32 @@ k01_binned(const float4* __restrict__ particles, const uint32_t* __restrict__ bi
         for (int i = threadIdx.x; i < PBIN_CELLS; i += 256) hist[i] = 0u;
         if (threadIdx.x < PBIN_BRICKS_Y) any[threadIdx.x] = 0;
         __syncthreads();
-        int rounds = 0;
-        for (uint32_t i0 = s; i0 < e; i0 += 256) {
-            const uint32_t i = i0 + threadIdx.x;
-            if (i < e) {
-                const float4 q = particles[i];
+        // four particles per thread and round, their loads in flight together (unconditional: a guarded load waits
+        // for the one before it); a stray that finds the workgroup's buffer full goes to the list by itself, so
+        // the loop has no barrier
+        for (uint32_t i0 = s; i0 < e; i0 += 4u * 256u) {
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = particles[min(i0 + (uint32_t)k * 256u + threadIdx.x, e - 1u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + (uint32_t)k * 256u + threadIdx.x;
                 int cx, cy, cz;
-                if (particle_cell(q, g, p, cx, cy, cz)) {
+                if (i < e && particle_cell(q[k], g, p, cx, cy, cz)) {
                     const int lx = cx - x0, ly = cy - y0, lz = cz - z0;
                     if (real && (unsigned)lx < (unsigned)PBIN_X && (unsigned)ly < (unsigned)PBIN_Y &&
-                        (unsigned)lz < (unsigned)PBIN_Z)
+                        (unsigned)lz < (unsigned)PBIN_Z) {
                         atomicAdd(&hist[lx + PBIN_X * (ly + PBIN_Y * lz)], 1u);
-                    else
-                        sbuf[atomicAdd(&sn, 1u)] = (uint32_t)cidx(g, cx, cy, cz);
+                    } else {
+                        const uint32_t key = (uint32_t)cidx(g, cx, cy, cz), slot = atomicAdd(&sn, 1u);
+                        if (slot < (uint32_t)K01_STRAY_BUF) {
+                            sbuf[slot] = key;
+                        } else {
+                            strays[atomicAdd(&stray_count[0], 1u)] = key;
+                            if (real) atomicAdd(&stray_count[1], 1u);
+                        }
+                    }
                 }
-            }
-            // a round adds at most 256 keys: empty the buffer before a fourth could overflow it
-            if (++rounds == K01_STRAY_BUF / 256 - 1) {
-                flush(real);
-                rounds = 0;
             }
         }
         flush(real);  // also the barrier in front of the histogram's readers
