@@ -362,8 +362,11 @@ struct BinTile {
 // Returns false — nothing sampled — when a tap lies outside the tile.
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 lerp2(pk2 A, pk2 B, pk2 a) { return ((pk2)(1.0f) - a) * A + a * B; }
-// axis_taps for coord + 0.5f (.x) and coord + 0.0f (.y) at once
-__device__ __forceinline__ void axis_taps2(float coord, const AxisN& ax, int (&i0)[2], int (&i1)[2], pk2& a) {
+// The lower tap of axis_taps for coord + 0.5f ([0], .x) and coord + 0.0f ([1], .y) at once, NOT clamped into the
+// image: lo in [-1, n].  The upper tap is lo + 1.  The bin's tile repeats the image's edge cells once beyond the
+// edge (k14_binned stages it so), so reading tile cells lo and lo + 1 gives what the clamped taps of axis_taps
+// give — and the eight taps of a sample sit at fixed distances from the first one.
+__device__ __forceinline__ void axis_lo2(float coord, const AxisN& ax, int (&lo)[2], pk2& a) {
     const pk2 c = (pk2)(coord) + (pk2){0.5f, 0.0f};
     pk2 u = c;  // a power of two: c / n * n gives c back where it matters (axis_taps)
     if (!ax.pow2) {
@@ -371,42 +374,43 @@ __device__ __forceinline__ void axis_taps2(float coord, const AxisN& ax, int (&i
         u = s * (pk2)(ax.fn);
     }
     const pk2 ub = u - (pk2)(0.5f);
-    pk2 fl = (pk2){floorf(ub.x), floorf(ub.y)};
+    const pk2 fl = (pk2){floorf(ub.x), floorf(ub.y)};
     a = ub - fl;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const float f = __builtin_amdgcn_fmed3f(k == 0 ? fl.x : fl.y, -1.0f, ax.fn);  // NaN -> -1 (axis_taps)
-        const int lo = (int)f;
-        i0[k] = clamp_index(lo, ax.n - 1);
-        i1[k] = min(lo + 1, ax.n - 1);
-    }
+    lo[0] = (int)__builtin_amdgcn_fmed3f(fl.x, -1.0f, ax.fn);  // NaN -> -1 (axis_taps)
+    lo[1] = (int)__builtin_amdgcn_fmed3f(fl.y, -1.0f, ax.fn);
 }
 __device__ __forceinline__ bool tile_velocity(const BinTile& t, const GridK& g, const Axes& axes, float px,
                                               float py, float pz, float& vx, float& vy, float& vz) {
-    int x0[2], x1[2], y0[2], y1[2], z0[2], z1[2];  // [0] staggered (+0.5), [1] not
+    int xl[2], yl[2], zl[2];  // [0] staggered (+0.5), [1] not
     pk2 ax, ay, az;
-    axis_taps2(px, axes.x, x0, x1, ax);
-    axis_taps2(py, axes.y, y0, y1, ay);
-    axis_taps2(pz, axes.z, z0, z1, az);
+    axis_lo2(px, axes.x, xl, ax);
+    axis_lo2(py, axes.y, yl, ay);
+    axis_lo2(pz, axes.z, zl, az);
     const int xo = t.x_org, yo = t.y_org, zo = t.z_org + g.z0;  // z taps are global planes
-    if (!((unsigned)(x0[1] - xo) < (unsigned)PTILE_W && (unsigned)(x1[0] - xo) < (unsigned)PTILE_W &&
-          (unsigned)(y0[1] - yo) < (unsigned)PTILE_H && (unsigned)(y1[0] - yo) < (unsigned)PTILE_H &&
-          (unsigned)(z0[1] - zo) < (unsigned)PTILE_D && (unsigned)(z1[0] - zo) < (unsigned)PTILE_D))
+    // all 24 taps inside the tile: the unstaggered pair starts lowest, the staggered pair ends highest
+    if (!((unsigned)(xl[1] - xo) < (unsigned)PTILE_W && (unsigned)(xl[0] + 1 - xo) < (unsigned)PTILE_W &&
+          (unsigned)(yl[1] - yo) < (unsigned)PTILE_H && (unsigned)(yl[0] + 1 - yo) < (unsigned)PTILE_H &&
+          (unsigned)(zl[1] - zo) < (unsigned)PTILE_D && (unsigned)(zl[0] + 1 - zo) < (unsigned)PTILE_D))
         return false;
-    // a Z slab: a tap beyond the ghost planes that hold the neighbouring slab's current data is the global
-    // sampler's business (it raises the halo-violation flag)
-    if (z0[1] - g.z0 < -g.sg_lo || z1[0] - g.z0 >= g.Dl + g.sg_hi) return false;
+    // a Z slab: a tap whose plane (clamped into the grid) lies beyond the ghost planes that hold the neighbouring
+    // slab's current data is the global sampler's business (it raises the halo-violation flag)
+    if (max(zl[1], 0) - g.z0 < -g.sg_lo || min(zl[0] + 1, g.Dg - 1) - g.z0 >= g.Dl + g.sg_hi) return false;
+    // byte offset of the first tap (lowest x, y, z) inside a component's array, axis by axis and stagger
+    int X[2], Y[2], Z[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        X[k] = 4 * (xl[k] - xo);
+        Y[k] = imul24(4 * PTILE_W, yl[k] - yo);
+        Z[k] = imul24(4 * PTILE_W * PTILE_H, zl[k] - zo);
+    }
     // component `c`, staggered on the axes whose s* flag is 0 ([0] = staggered taps)
     auto tri = [&](const FLUID_LDS_F float* c, int sx, int sy, int sz) {
-        const int r00 = PTILE_W * ((y0[sy] - yo) + PTILE_H * (z0[sz] - zo)) - xo;
-        const int r10 = PTILE_W * ((y1[sy] - yo) + PTILE_H * (z0[sz] - zo)) - xo;
-        const int r01 = PTILE_W * ((y0[sy] - yo) + PTILE_H * (z1[sz] - zo)) - xo;
-        const int r11 = PTILE_W * ((y1[sy] - yo) + PTILE_H * (z1[sz] - zo)) - xo;
+        const FLUID_LDS_F float* q = reinterpret_cast<const FLUID_LDS_F float*>(
+            reinterpret_cast<const FLUID_LDS_F char*>(c) + (X[sx] + Y[sy] + Z[sz]));
+        constexpr int DY = PTILE_W, DZ = PTILE_W * PTILE_H;
         const float wx = sx ? ax.y : ax.x, wy = sy ? ay.y : ay.x;
-        const pk2 cz0 = lerp2((pk2){c[r00 + x0[sx]], c[r10 + x0[sx]]}, (pk2){c[r00 + x1[sx]], c[r10 + x1[sx]]},
-                              (pk2)(wx));  // c00, c10
-        const pk2 cz1 = lerp2((pk2){c[r01 + x0[sx]], c[r11 + x0[sx]]}, (pk2){c[r01 + x1[sx]], c[r11 + x1[sx]]},
-                              (pk2)(wx));  // c01, c11
+        const pk2 cz0 = lerp2((pk2){q[0], q[DY]}, (pk2){q[1], q[DY + 1]}, (pk2)(wx));                      // c00, c10
+        const pk2 cz1 = lerp2((pk2){q[DZ], q[DZ + DY]}, (pk2){q[DZ + 1], q[DZ + DY + 1]}, (pk2)(wx));      // c01, c11
         return lerp2((pk2){cz0.x, cz1.x}, (pk2){cz0.y, cz1.y}, (pk2)(wy));  // c0, c1
     };
     const pk2 cx = tri(t.comp[0], 0, 1, 1), cy = tri(t.comp[1], 1, 0, 1), cz = tri(t.comp[2], 1, 1, 0);
@@ -457,10 +461,12 @@ k14_binned(const float4* __restrict__ v1, float4* __restrict__ particles,
         t.z_org = (byz / b.ny) * PBIN_Z - 1;
         __syncthreads();  // the previous bin's taps are done with the tile
         for (int c = threadIdx.x; c < PTILE_CELLS; c += 256) {
-            const int x = t.x_org + c % PTILE_W, y = t.y_org + (c / PTILE_W) % PTILE_H,
-                      z = t.z_org + c / (PTILE_W * PTILE_H);
+            // a tile cell beyond an edge of the grid repeats the edge cell (tile_velocity reads unclamped taps)
+            const int x = min(max(t.x_org + c % PTILE_W, 0), g.W - 1);
+            const int y = min(max(t.y_org + (c / PTILE_W) % PTILE_H, 0), g.H - 1);
+            const int z = min(max(g.z0 + t.z_org + c / (PTILE_W * PTILE_H), 0), g.Dg - 1) - g.z0;
             // (local planes; a slab's ghost planes are loaded too — whether a tap may use them is tile_velocity's test)
-            if ((unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H && z >= -IMG_GHOST && z < g.Dl + IMG_GHOST) {
+            if (z >= -IMG_GHOST && z < g.Dl + IMG_GHOST) {
                 const float4 v = v1[cidx(g, x, y, z)];
                 tile[0][c] = v.x;
                 tile[1][c] = v.y;

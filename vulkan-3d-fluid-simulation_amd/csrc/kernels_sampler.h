@@ -45,6 +45,9 @@ __device__ __forceinline__ int clamp_index(int i, int last) {
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(last));
     return r;
 }
+// product of two small integers (tile indices): v_mul_i32_i24 runs at full rate, the 32-bit v_mul_lo_u32 hipcc
+// takes for an int product at a quarter of it
+__device__ __forceinline__ int imul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0, int& i1, float& a) {
     const int n = ax.n;
     const float fn = ax.fn;
@@ -134,8 +137,8 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
                     (unsigned)ty0 < (unsigned)TH && (unsigned)ty1 < (unsigned)TH && tz0 >= 0 && tz1 >= 0;
         if (from_tile) {
             const FLUID_LDS_F float* t = tile.comp[COMP];
-            const int r00 = TW * (ty0 + TH * tz0), r10 = TW * (ty1 + TH * tz0);
-            const int r01 = TW * (ty0 + TH * tz1), r11 = TW * (ty1 + TH * tz1);
+            const int r00 = imul24(TW, ty0 + TH * tz0), r10 = imul24(TW, ty1 + TH * tz0);
+            const int r01 = imul24(TW, ty0 + TH * tz1), r11 = imul24(TW, ty1 + TH * tz1);
             c000 = t[r00 + tx0]; c100 = t[r00 + tx1];
             c010 = t[r10 + tx0]; c110 = t[r10 + tx1];
             c001 = t[r01 + tx0]; c101 = t[r01 + tx1];
@@ -180,7 +183,7 @@ __device__ __forceinline__ float3 face_velocity(const VelTile& tile, const GridK
     const int tym = ty - (y > 0), typ = ty + (y < g.H - 1);
     const int tzm = tile.slot(lz - (gz > 0)), tzp = tile.slot(lz + (gz < g.Dg - 1));
     auto at = [&](int comp, int ax, int ay, int az) {
-        return tile.comp[comp][ax + TILE_W * (ay + TILE_H * az)];
+        return tile.comp[comp][ax + imul24(TILE_W, ay + TILE_H * az)];
     };
     auto half = [](float A, float B) { return (1.0f - 0.5f) * A + 0.5f * B; };  // lerp1(A, B, 0.5f)
     float3 v;
