@@ -141,8 +141,8 @@ __global__ void k03_update_air_v4(uint8_t* __restrict__ t, GridK g, ParamsK p,
                    zp_b = gz + 1 == g.Dg - 1;
         const uint32_t ym = word(y - 1, lz), yp = word(y + 1, lz);
         const uint32_t zm = word(y, lz - 1), zp = word(y, lz + 1);
-        const uint32_t left = x > 0 ? (uint32_t)t[id - 1] : 0u;
-        const uint32_t right = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+        const uint32_t left_ = t[id - (x > 0 ? 1 : 0)], right_ = t[id + (x + 4 < g.W ? 4 : 3)];
+        const uint32_t left = x > 0 ? left_ : 0u, right = x + 4 < g.W ? right_ : 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int xi = x + i;
@@ -319,21 +319,25 @@ __global__ void k13_fix_divergence(const uint8_t* __restrict__ t, const float* _
     FLUID_FOR_CELLS_OF_ROW(xchunks)
     const int64_t id = cidx(g, x, y, lz);
     const int gz = g.z0 + lz;
+    // all loads first, at addresses that exist whatever the cell (k091011_solids_divergence has the reason)
+    const int64_t nb[3] = {id - (x > 0 ? 1 : 0), id - (y > 0 ? g.W : 0), id - g.plane};  // :43
     const uint32_t lt = t[id];  // :62
     const float lp = pr[id];    // :63
+    const uint32_t nt[3] = {t[nb[0]], t[nb[1]], t[nb[2]]};  // :44
+    const float np[3] = {pr[nb[0]], pr[nb[1]], pr[nb[2]]};
+    float4 q = v1[id];
     const float k = (p.dt / p.rho) / p.dx;  // :71
     const int pos[3] = {x, y, gz};
     float dv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int nx = x - (c == 0), ny = y - (c == 1), nlz = lz - (c == 2);  // :43
-        const uint32_t ct = type_at(t, g, nx, ny, nlz);                       // :44
+        // (pos[c] == 0: no neighbour, or — z — the plane below a slab's face at the domain's floor; :46 skips it)
+        const uint32_t ct = nt[c];
         if (pos[c] != 0 && (lt == p.t_water || ct == p.t_water)) {            // :46
             if (lt != p.t_solid && ct != p.t_solid)                           // :48
-                dv[c] = lp - pr[cidx(g, nx, ny, nlz)];                        // :50
+                dv[c] = lp - np[c];                                           // :50
         }
     }
-    float4 q = v1[id];
     q.x = q.x - k * dv[0];
     q.y = q.y - k * dv[1];
     q.z = q.z - k * dv[2];

@@ -12,9 +12,12 @@ namespace fluid {
 
 __device__ __forceinline__ uint32_t ld_types4(const uint8_t* __restrict__ t, const GridK& g, int x,
                                               int y, int lz) {
-    // four cell types starting at x (x % 4 == 0, W % 4 == 0); a row outside the grid reads as 0
-    if ((unsigned)x >= (unsigned)g.W || (unsigned)y >= (unsigned)g.H) return 0u;
-    return *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz));
+    // four cell types starting at x (x % 4 == 0, W % 4 == 0); a row outside the grid reads as 0.  The load itself is
+    // unconditional (at the image's first word of the plane when the row does not exist): a load behind a bounds
+    // test waits for the loads before it
+    const bool in = (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(t + cidx(g, in ? x : 0, in ? y : 0, lz));
+    return in ? w : 0u;
 }
 __device__ __forceinline__ uint32_t byte_at(uint32_t w, int i) { return (w >> (8 * i)) & 0xFFu; }
 
@@ -47,8 +50,8 @@ __global__ void k12_prepare_v4(const uint8_t* __restrict__ t, const float* __res
         const uint32_t yp = ld_types4(t, g, x, y + 1, lz), ym = ld_types4(t, g, x, y - 1, lz);
         const uint32_t zp = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz + 1));
         const uint32_t zm = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz - 1));
-        const uint32_t left = x > 0 ? (uint32_t)t[id - 1] : 0u;
-        const uint32_t right = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+        const uint32_t left_ = t[id - (x > 0 ? 1 : 0)], left = x > 0 ? left_ : 0u;
+        const uint32_t right_ = t[id + (x + 4 < g.W ? 4 : 3)], right = x + 4 < g.W ? right_ : 0u;
         uint32_t out = 0;
         bool any_water = false;
 #pragma unroll
@@ -289,7 +292,8 @@ __global__ void k12_sor_colour_v4(const uint8_t* __restrict__ t, const float* __
     const uint32_t typ = ld_types4(t, g, x, y + 1, lz), tym = ld_types4(t, g, x, y - 1, lz);
     const uint32_t tzp = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz + 1));
     const uint32_t tzm = *reinterpret_cast<const uint32_t*>(t + cidx(g, x, y, lz - 1));
-    const uint32_t tl = x > 0 ? (uint32_t)t[id - 1] : 0u, tr = x + 4 < g.W ? (uint32_t)t[id + 4] : 0u;
+    const uint32_t tl_ = t[id - (x > 0 ? 1 : 0)], tr_ = t[id + (x + 4 < g.W ? 4 : 3)];
+    const uint32_t tl = x > 0 ? tl_ : 0u, tr = x + 4 < g.W ? tr_ : 0u;
     auto prow = [&](int ny) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)ny < (unsigned)g.H) v = *reinterpret_cast<const float4*>(pr + cidx(g, x, ny, lz));

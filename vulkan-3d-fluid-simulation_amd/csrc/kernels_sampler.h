@@ -210,11 +210,14 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
                                                   int lz, int gz,
                                                   bool cur_water, float keep,
                                                   uint32_t* __restrict__ violation,
-                                                  const Tile& tile = Tile(), bool fast_faces = false) {
+                                                  const Tile& tile = Tile(), bool fast_faces = false,
+                                                  uint32_t nt_loaded = 0xFFFFFFFFu) {
     const int pos = COMP == 0 ? x : (COMP == 1 ? y : gz);
     // advect.comp:65-68: move[c] = -1; cellAt(pos - move) is the cell at pos + e_c
-    const uint32_t nt =
-        type_at(t, g, x + (COMP == 0), y + (COMP == 1), lz + (COMP == 2));
+    // (nt_loaded: the caller has that cell's type already, type_at's 0 for a cell outside the image included)
+    const uint32_t nt = nt_loaded != 0xFFFFFFFFu
+                            ? nt_loaded
+                            : type_at(t, g, x + (COMP == 0), y + (COMP == 1), lz + (COMP == 2));
     if (pos != 0 && (cur_water || nt == p.t_water)) {
         const float qx = (float)x + (COMP == 0 ? 0.0f : 0.5f);  // :70-73
         const float qy = (float)y + (COMP == 1 ? 0.0f : 0.5f);
@@ -244,8 +247,8 @@ __device__ __forceinline__ float advect_component(const uint8_t* __restrict__ t,
 // 08_forces on the value 07 produced (forces.comp:33-54), shared by both advect kernels
 __device__ __forceinline__ float4 forces_on(float4 o, const uint8_t* __restrict__ t, const GridK& g,
                                             const ParamsK& p, int x, int y, int lz, int gz,
-                                            bool cur_water) {
-    const uint32_t t2 = type_at(t, g, x, y - 1, lz);
+                                            bool cur_water, uint32_t below_loaded = 0xFFFFFFFFu) {
+    const uint32_t t2 = below_loaded != 0xFFFFFFFFu ? below_loaded : type_at(t, g, x, y - 1, lz);
     const bool wet = cur_water || (t2 == p.t_water);
     float fy = 0.0f;
     if (y != 0 && wet) fy += p.gravity;  // :39-45
@@ -383,20 +386,32 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
         // shortcut cannot take (per thread; the caller votes)
         auto stage = [&](int cz, int sl) -> bool {
             bool special = false;
-            if (cz >= zlo && cz <= zhi)
-                for (int i = tid; i < TILE_W * TILE_H; i += 256) {
-                    const int tx = i % TILE_W, ty = i / TILE_W;
-                    const int cx = tile.x_org + tx, cy = tile.y_org + ty;
-                    if ((unsigned)cx < (unsigned)g.W && (unsigned)cy < (unsigned)g.H) {
-                        const float4 q = v1[cidx(g, cx, cy, cz)];
+            if (cz >= zlo && cz <= zhi) {
+                // the thread's (up to) three texels, their loads in flight together: a tile cell outside the image
+                // takes the nearest cell inside (nobody reads it: taps are clamped into the image before the lookup),
+                // so no load sits behind a bounds test
+                constexpr int PER = (TILE_W * TILE_H + 255) / 256;
+                float4 q[PER];
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const int i = min(tid + 256 * j, TILE_W * TILE_H - 1);
+                    const int cx = min(max(tile.x_org + i % TILE_W, 0), g.W - 1);
+                    const int cy = min(max(tile.y_org + i / TILE_W, 0), g.H - 1);
+                    q[j] = v1[cidx(g, cx, cy, cz)];
+                }
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const int i = tid + 256 * j;
+                    if (i < TILE_W * TILE_H) {
                         const int o = i + TILE_W * TILE_H * sl;
-                        tile_mem[0][o] = q.x;
-                        tile_mem[1][o] = q.y;
-                        tile_mem[2][o] = q.z;
-                        special = special || sampler_special_value(q.x) || sampler_special_value(q.y) ||
-                                  sampler_special_value(q.z);
+                        tile_mem[0][o] = q[j].x;
+                        tile_mem[1][o] = q[j].y;
+                        tile_mem[2][o] = q[j].z;
+                        special = special || sampler_special_value(q[j].x) || sampler_special_value(q[j].y) ||
+                                  sampler_special_value(q[j].z);
                     }
                 }
+            }
             return special;
         };
         // The window is staged lazily: planes [have_lo, have_hi) are in the ring, plane z in slot
@@ -410,13 +425,22 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
             int64_t id = 0;
             float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
             bool cur_water = false, adv = false;
+            uint32_t txp = 0u, typ = 0u, tzp = 0u, tym = 0u;  // types of the +x, +y, +z and -y neighbours (type_at)
             if (valid) {
+                // the cell's five type bytes and its velocity, all issued before the first one is used (behind
+                // type_at's bounds tests and a short-circuit || each load waited for the one before)
                 id = cidx(g, x, y, lz);
+                const bool has_xp = x + 1 < g.W, has_yp = y + 1 < g.H, has_ym = y > 0;
                 cur = v1[id];                                   // :87
-                cur_water = (uint32_t)t[id] == p.t_water;       // :93
-                adv = cur_water || type_at(t, g, x + 1, y, lz) == p.t_water ||
-                      type_at(t, g, x, y + 1, lz) == p.t_water ||
-                      (uint32_t)t[cidx(g, x, y, lz + 1)] == p.t_water;
+                const uint32_t tc = t[id];
+                const uint32_t a = t[id + (has_xp ? 1 : 0)], b = t[id + (has_yp ? g.W : 0)], c = t[id + g.plane],
+                               d = t[id - (has_ym ? g.W : 0)];
+                txp = has_xp ? a : 0u;
+                typ = has_yp ? b : 0u;
+                tzp = c;
+                tym = has_ym ? d : 0u;
+                cur_water = tc == p.t_water;                    // :93
+                adv = cur_water || txp == p.t_water || typ == p.t_water || tzp == p.t_water;
             }
             // the vote is also the barrier behind the previous plane's reads of the window
             const bool any_adv = wg_or(adv ? 1u : 0u) != 0u;
@@ -442,16 +466,16 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
                 const bool fast_faces = pow2_grid && (bad & faces) == 0u;
                 if (adv) {
                     o.x = advect_component<0, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.x,
-                                                       violation, tile, fast_faces);
+                                                       violation, tile, fast_faces, txp);
                     o.y = advect_component<1, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.y,
-                                                       violation, tile, fast_faces);
+                                                       violation, tile, fast_faces, typ);
                     o.z = advect_component<2, VelTile>(t, v1, g, axes, p, x, y, lz, gz, cur_water, cur.z,
-                                                       violation, tile, fast_faces);
+                                                       violation, tile, fast_faces, tzp);
                 }
             }
             if (valid) {
                 o.w = 0.0f;
-                if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water);
+                if (FORCES) o = forces_on(o, t, g, p, x, y, lz, gz, cur_water, tym);
                 v2[id] = o;  // :96
             }
         }

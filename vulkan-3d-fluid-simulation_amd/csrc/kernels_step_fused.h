@@ -117,9 +117,14 @@ __device__ __forceinline__ uint32_t activity_states4(const uint8_t* __restrict__
     auto word = [&](const uint8_t* t, int64_t at) { return *reinterpret_cast<const uint32_t*>(t + at); };
     const uint32_t o_c = word(oldT, id), n_c = word(newT, id);
     // -y neighbours: out of bounds reads as type 0 (device_common.h: type_at); -z: ghost planes
-    const uint32_t o_y = y > 0 ? word(oldT, id - g.W) : 0u, n_y = y > 0 ? word(newT, id - g.W) : 0u;
+    // (every load unconditional, at the cell itself where the neighbour does not exist, its value dropped by a
+    // select: a load behind a bounds test waits for the loads before it)
+    const int64_t iy = id - (y > 0 ? g.W : 0), il = id - (x > 0 ? 1 : 0);
+    const uint32_t o_y_ = word(oldT, iy), n_y_ = word(newT, iy);
     const uint32_t o_z = word(oldT, id - g.plane), n_z = word(newT, id - g.plane);
-    const uint32_t o_l = x > 0 ? (uint32_t)oldT[id - 1] : 0u, n_l = x > 0 ? (uint32_t)newT[id - 1] : 0u;
+    const uint32_t o_l_ = oldT[il], n_l_ = newT[il];
+    const uint32_t o_y = y > 0 ? o_y_ : 0u, n_y = y > 0 ? n_y_ : 0u;
+    const uint32_t o_l = x > 0 ? o_l_ : 0u, n_l = x > 0 ? n_l_ : 0u;
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -242,22 +247,28 @@ __global__ void k091011_solids_divergence(const uint8_t* __restrict__ t,
     const int64_t id = cidx(g, x, y, lz);
     const int gz = g.z0 + lz;
     const float r = p.repel;
+    // Every load of the cell is issued before the first one is used, at an address that exists whatever the cell
+    // (a neighbour outside the image: the cell itself, its value dropped by a select) — behind a bounds test each
+    // load would wait for the one before it, five memory round trips in a row.
+    const bool has_xm = x > 0, has_ym = y > 0, has_xp = x + 1 < g.W, has_yp = y + 1 < g.H;
+    const bool has_zp = gz + 1 < g.Dg;  // on a Z slab the plane above the slab is a ghost plane of VELOCITIES_2 / types
+    const int64_t ixp = id + (has_xp ? 1 : 0), iyp = id + (has_yp ? g.W : 0), izp = id + (has_zp ? g.plane : 0);
     const float4 q = v2[id];  // diffuse.comp:34,46: the copy
-    const bool solid = (uint32_t)t[id] == p.t_solid;
-    const float vx = solids_component(q.x, solid, type_at(t, g, x - 1, y, lz) == p.t_solid, r);
-    const float vy = solids_component(q.y, solid, type_at(t, g, x, y - 1, lz) == p.t_solid, r);
-    const float vz = solids_component(q.z, solid, (uint32_t)t[id - g.plane] == p.t_solid, r);
+    const uint32_t tc = t[id], txm = t[id - (has_xm ? 1 : 0)], tym = t[id - (has_ym ? g.W : 0)], tzm = t[id - g.plane];
+    const uint32_t txp = t[ixp], typ = t[iyp], tzp = t[izp];
+    const float qxp = v2[ixp].x, qyp = v2[iyp].y, qzp = v2[izp].z;
+    const bool solid = tc == p.t_solid;
+    // (a neighbour outside the image has type 0: type_at)
+    const float vx = solids_component(q.x, solid, (has_xm ? txm : 0u) == p.t_solid, r);
+    const float vy = solids_component(q.y, solid, (has_ym ? tym : 0u) == p.t_solid, r);
+    const float vz = solids_component(q.z, solid, tzm == p.t_solid, r);
     v1[id] = make_float4(vx, vy, vz, 1.0f);  // solids.comp:76
     // compute_divergence.comp:18-30 on the field 10 produces: the +x/+y/+z neighbours' components go
     // through 10 here as well (their lower neighbour along that axis is this cell); outside the grid the
     // image load returns 0
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    if (x + 1 < g.W)
-        ax = solids_component(v2[id + 1].x, (uint32_t)t[id + 1] == p.t_solid, solid, r);
-    if (y + 1 < g.H)
-        ay = solids_component(v2[id + g.W].y, (uint32_t)t[id + g.W] == p.t_solid, solid, r);
-    if (gz + 1 < g.Dg)  // on a Z slab the plane above the slab is a ghost plane of VELOCITIES_2 / types
-        az = solids_component(v2[id + g.plane].z, (uint32_t)t[id + g.plane] == p.t_solid, solid, r);
+    const float ax = has_xp ? solids_component(qxp, txp == p.t_solid, solid, r) : 0.0f;
+    const float ay = has_yp ? solids_component(qyp, typ == p.t_solid, solid, r) : 0.0f;
+    const float az = has_zp ? solids_component(qzp, tzp == p.t_solid, solid, r) : 0.0f;
     float d = ax - vx;  // :21 left to right
     d = d + ay;
     d = d - vy;
