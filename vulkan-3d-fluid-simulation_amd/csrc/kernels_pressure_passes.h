@@ -129,13 +129,16 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
     FLUID_V4_THREAD();
     FLUID_FOR_PLANES_OF_WORKGROUP() {
     const int64_t id = cidx(g, x, y, lz);
+    // (the iterates are loaded with the types, not behind the test of the types: one memory round trip, not two)
     const uint32_t c = *reinterpret_cast<const uint32_t*>(t + id);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ve = w_even ? *reinterpret_cast<const float4*>(w_even + id) : zero;
+    const float4 vo = w_odd ? *reinterpret_cast<const float4*>(w_odd + id) : zero;
     const bool w[4] = {byte_at(c, 0) == p.t_water, byte_at(c, 1) == p.t_water,
                        byte_at(c, 2) == p.t_water, byte_at(c, 3) == p.t_water};
     if (!(w[0] || w[1] || w[2] || w[3])) continue;  // pressure.comp:69: non-water cells are never written
     const bool all = w[0] && w[1] && w[2] && w[3];
-    auto put = [&](const float* src, float* dst) {
-        const float4 v = *reinterpret_cast<const float4*>(src + id);
+    auto put = [&](const float4& v, float* dst) {
         if (all) {
             *reinterpret_cast<float4*>(dst + id) = v;
         } else {
@@ -145,8 +148,8 @@ __global__ void k12_export_v4(const uint8_t* __restrict__ t, const float* __rest
             if (w[3]) dst[id + 3] = v.w;
         }
     };
-    if (w_even) put(w_even, p1);
-    if (w_odd) put(w_odd, p2);
+    if (w_even) put(ve, p1);
+    if (w_odd) put(vo, p2);
     }  // planes of the workgroup
 }
 
