@@ -160,17 +160,50 @@ struct FusedCtxT {
 // neighbours (mask word 0x06060606 in all lanes: the inside of a body of water — most of a full tank): aii and its
 // reciprocal are constants and no cell keeps its old value, which leaves the numerators and the three-instruction
 // quotients — about half the instructions of the general form.
+// (Packed arithmetic like canon_lane_pk below: two cells per instruction.)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <bool ZEROS_QUICK>
 __device__ __forceinline__ float4 canon_lane_all6(float4 b, float4 c, float4 yp, float4 zp, float4 ym, float4 zm,
                                                   float left, float right) {
-    float4 n;
-    n.x = canon_num(b.x, c.y, yp.x, zp.x, left, ym.x, zm.x);
-    n.y = canon_num(b.y, c.z, yp.y, zp.y, c.x, ym.y, zm.y);
-    n.z = canon_num(b.z, c.w, yp.z, zp.z, c.y, ym.z, zm.z);
-    n.w = canon_num(b.w, right, yp.w, zp.w, c.z, ym.w, zm.w);
-    DivPairs d;
-    d.c[0] = d.c[1] = d.c[2] = d.c[3] = make_float2(6.0f, 0x1.555556p-3f);  // RN(1 / 6)
-    return canon_div4<ZEROS_QUICK>(n, 0x06060606u, d);
+    const f32x2_t w0 = {left, c.x}, w1 = {c.y, c.z}, w2 = {c.w, right};
+    f32x2_t s01 = {b.x, b.y}, s23 = {b.z, b.w};
+    s01 = s01 - w1;                      // + x   (pressure.comp:56-61 order: +x, +y, +z, -x, -y, -z)
+    s23 = s23 - w2;
+    s01 = s01 - (f32x2_t){yp.x, yp.y};   // + y
+    s23 = s23 - (f32x2_t){yp.z, yp.w};
+    s01 = s01 - (f32x2_t){zp.x, zp.y};   // + z
+    s23 = s23 - (f32x2_t){zp.z, zp.w};
+    s01 = s01 - w0;                      // - x
+    s23 = s23 - w1;
+    s01 = s01 - (f32x2_t){ym.x, ym.y};   // - y
+    s23 = s23 - (f32x2_t){ym.z, ym.w};
+    s01 = s01 - (f32x2_t){zm.x, zm.y};   // - z
+    s23 = s23 - (f32x2_t){zm.z, zm.w};
+    const f32x2_t n01 = -s01, n23 = -s23;
+    const f32x2_t a = {6.0f, 6.0f}, r = {0x1.555556p-3f, 0x1.555556p-3f};  // aii and RN(1 / 6)
+    const float least = fminf(fminf(fabsf(n01.x), fabsf(n01.y)), fminf(fabsf(n23.x), fabsf(n23.y)));
+    bool slow = __builtin_amdgcn_ballot_w64(least < 0x1p-100f) != 0ull;  // the tiny-numerator test of canon_div4
+    if (slow && ZEROS_QUICK) {
+        const int ex = min(min(__builtin_amdgcn_frexp_expf(n01.x), __builtin_amdgcn_frexp_expf(n01.y)),
+                           min(__builtin_amdgcn_frexp_expf(n23.x), __builtin_amdgcn_frexp_expf(n23.y)));
+        slow = __builtin_amdgcn_ballot_w64(ex < -99) != 0ull;  // only zeros were small: quick
+    }
+    float4 o;
+    if (!slow) {  // div_small_int, two cells at a time
+        const f32x2_t p01 = n01 * r, p23 = n23 * r;
+        const f32x2_t e01 = __builtin_elementwise_fma(-p01, a, n01), e23 = __builtin_elementwise_fma(-p23, a, n23);
+        const f32x2_t q01 = __builtin_elementwise_fma(e01, r, p01), q23 = __builtin_elementwise_fma(e23, r, p23);
+        o.x = __builtin_amdgcn_div_fixupf(q01.x, 6.0f, n01.x);
+        o.y = __builtin_amdgcn_div_fixupf(q01.y, 6.0f, n01.y);
+        o.z = __builtin_amdgcn_div_fixupf(q23.x, 6.0f, n23.x);
+        o.w = __builtin_amdgcn_div_fixupf(q23.y, 6.0f, n23.y);
+    } else {  // some 0 < |n| < 2^-100 in this wavefront: the IEEE sequence for all its lanes
+        o.x = n01.x / 6.0f;
+        o.y = n01.y / 6.0f;
+        o.z = n23.x / 6.0f;
+        o.w = n23.y / 6.0f;
+    }
+    return o;
 }
 
 // canon_lane of kernels_pressure_fused.h on pairs of cells: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on two
@@ -178,7 +211,6 @@ __device__ __forceinline__ float4 canon_lane_all6(float4 b, float4 c, float4 yp,
 // from: 16 lanes per SIMD and clock, two floats each), each element rounded as the scalar instruction rounds it — so
 // the six subtractions and the three-instruction quotient of a lane's four cells take half the instructions, bit for
 // bit the same.  The x neighbours of cells (0, 1) and (2, 3) are the pairs (left, c.x), (c.y, c.z), (c.w, right).
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <bool ZEROS_QUICK>
 __device__ __forceinline__ float4 canon_lane_pk(float4 b, uint32_t m, float4 c, float4 yp, float4 zp, float4 ym,
                                                 float4 zm, float left, float right) {
