@@ -48,8 +48,8 @@ __device__ __forceinline__ int clamp_index(int i, int last) {
 // product of two small integers (tile indices): v_mul_i32_i24 runs at full rate, the 32-bit v_mul_lo_u32 hipcc
 // takes for an int product at a quarter of it
 __device__ __forceinline__ int imul24(int a, int b) { return __mul24(a, b); }
-__device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0, int& i1, float& a) {
-    const int n = ax.n;
+// The lower tap before it is clamped into the image, lo in [-1, n] (the upper tap is lo + 1), and the weight.
+__device__ __forceinline__ void axis_lo(float coord, const AxisN& ax, int& lo, float& a) {
     const float fn = ax.fn;
     // u = coord / n * n.  For n a power of two the quotient is coord * 2^-k, exactly, and the product gives
     // coord back — unless the quotient is subnormal and loses bits, but then |coord| < 2^-100 and ub below is
@@ -67,9 +67,13 @@ __device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0,
     // fl into [-1, n]: v_med3_f32 returns the minimum of its operands when one is NaN, i.e. -1, which is what
     // "if (!(fl >= -1)) fl = -1; if (fl > fn) fl = fn" makes of a NaN too
     fl = __builtin_amdgcn_fmed3f(fl, -1.0f, fn);
-    const int lo = (int)fl;
-    i0 = clamp_index(lo, n - 1);
-    i1 = min(lo + 1, n - 1);  // lo + 1 >= 0 already
+    lo = (int)fl;
+}
+__device__ __forceinline__ void axis_taps(float coord, const AxisN& ax, int& i0, int& i1, float& a) {
+    int lo;
+    axis_lo(coord, ax, lo, a);
+    i0 = clamp_index(lo, ax.n - 1);
+    i1 = min(lo + 1, ax.n - 1);  // lo + 1 >= 0 already
 }
 __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f - a) * A + a * B; }
 
@@ -78,7 +82,7 @@ __device__ __forceinline__ float lerp1(float A, float B, float a) { return (1.0f
 // plane that enters overwrites the one that left); one array per component so that neighbouring lanes read
 // neighbouring banks.  Tile cell (tx, ty, slot) holds the texel at grid index (x_org + tx, y_org + ty, local
 // plane z): slot(z) = (z - z_lo + z_rot) mod TILE_D for the planes z_lo .. z_lo + TILE_D - 1 of the window;
-// cells outside the image are never addressed (taps are clamped into the image before the lookup).
+// tile cells outside the image repeat the image's edge texel (sample_comp reads x and y taps before they are clamped).
 #define FLUID_LDS_F __attribute__((address_space(3)))
 constexpr int TILE_HALO = 2;
 constexpr int TILE_W = 64 + 2 * TILE_HALO, TILE_H = 4 + 2 * TILE_HALO, TILE_D = 1 + 2 * TILE_HALO;
@@ -110,10 +114,10 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
                                              const Tile& tile = Tile()) {
     const float mx = COMP == 0 ? 0.5f : 0.0f, my = COMP == 1 ? 0.5f : 0.0f,
                 mz = COMP == 2 ? 0.5f : 0.0f;
-    int x0, x1, y0, y1, z0, z1;
+    int xl, yl, z0, z1;  // x, y: the lower tap, not clamped yet (the tile path does not need it clamped)
     float ax, ay, az;
-    axis_taps(px + mx, axes.x, x0, x1, ax);
-    axis_taps(py + my, axes.y, y0, y1, ay);
+    axis_lo(px + mx, axes.x, xl, ax);
+    axis_lo(py + my, axes.y, yl, ay);
     axis_taps(pz + mz, axes.z, z0, z1, az);
     z0 -= g.z0;
     z1 -= g.z0;
@@ -130,24 +134,27 @@ __device__ __forceinline__ float sample_comp(const float4* __restrict__ v, const
     float c000 = 0.f, c100 = 0.f, c010 = 0.f, c110 = 0.f, c001 = 0.f, c101 = 0.f, c011 = 0.f, c111 = 0.f;
     bool from_tile = false;
     if constexpr (Tile::enabled) {
-        const int tx0 = x0 - tile.x_org, tx1 = x1 - tile.x_org, ty0 = y0 - tile.y_org,
-                  ty1 = y1 - tile.y_org, tz0 = tile.slot(z0), tz1 = tile.slot(z1);
+        // The tile repeats the image's edge texels once beyond the edge (k07_advect_tiled stages it so): texels
+        // xl and xl + 1 of the tile are what the clamped taps of axis_taps are in the image, and the four taps of a
+        // plane sit at fixed distances from the first — one address per plane, two ds_read2_b32.
+        const int tx = xl - tile.x_org, ty = yl - tile.y_org, tz0 = tile.slot(z0), tz1 = tile.slot(z1);
         constexpr int TW = Tile::W, TH = Tile::H;
-        from_tile = (unsigned)tx0 < (unsigned)TW && (unsigned)tx1 < (unsigned)TW &&
-                    (unsigned)ty0 < (unsigned)TH && (unsigned)ty1 < (unsigned)TH && tz0 >= 0 && tz1 >= 0;
+        from_tile = (unsigned)tx < (unsigned)(TW - 1) && (unsigned)ty < (unsigned)(TH - 1) && tz0 >= 0 && tz1 >= 0;
         if (from_tile) {
-            const FLUID_LDS_F float* t = tile.comp[COMP];
-            const int r00 = imul24(TW, ty0 + TH * tz0), r10 = imul24(TW, ty1 + TH * tz0);
-            const int r01 = imul24(TW, ty0 + TH * tz1), r11 = imul24(TW, ty1 + TH * tz1);
-            c000 = t[r00 + tx0]; c100 = t[r00 + tx1];
-            c010 = t[r10 + tx0]; c110 = t[r10 + tx1];
-            c001 = t[r01 + tx0]; c101 = t[r01 + tx1];
-            c011 = t[r11 + tx0]; c111 = t[r11 + tx1];
+            const int row = tx + imul24(TW, ty);
+            const FLUID_LDS_F float* t0 = tile.comp[COMP] + (row + imul24(TW * TH, tz0));
+            const FLUID_LDS_F float* t1 = tile.comp[COMP] + (row + imul24(TW * TH, tz1));
+            c000 = t0[0];  c100 = t0[1];
+            c010 = t0[TW]; c110 = t0[TW + 1];
+            c001 = t1[0];  c101 = t1[1];
+            c011 = t1[TW]; c111 = t1[TW + 1];
         }
     }
     if (!from_tile) {
         // one 64-bit texel address (the corner x0, y0, z0), the other seven taps at small 32-bit offsets
         // from it: the steps along the axes are 0 or 1 texel (0 where the tap is clamped at an edge)
+        const int x0 = clamp_index(xl, g.W - 1), x1 = min(xl + 1, g.W - 1);
+        const int y0 = clamp_index(yl, g.H - 1), y1 = min(yl + 1, g.H - 1);
         const float* __restrict__ f = reinterpret_cast<const float*>(v + cidx(g, x0, y0, z0)) + COMP;
         const int dx = 4 * (x1 - x0), dy = 4 * (y1 - y0) * g.W, dz = 4 * (z1 - z0) * (int)g.plane;
         c000 = f[0];       c100 = f[dx];
@@ -388,7 +395,7 @@ k07_advect_tiled(const uint8_t* __restrict__ t, const float4* __restrict__ v1,
             bool special = false;
             if (cz >= zlo && cz <= zhi) {
                 // the thread's (up to) three texels, their loads in flight together: a tile cell outside the image
-                // takes the nearest cell inside (nobody reads it: taps are clamped into the image before the lookup),
+                // takes the nearest cell inside (what the sampler's clamp would read there: sample_comp relies on it),
                 // so no load sits behind a bounds test
                 constexpr int PER = (TILE_W * TILE_H + 255) / 256;
                 float4 q[PER];
