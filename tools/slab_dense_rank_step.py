@@ -17,9 +17,15 @@ p.particle_spawn_cube_volume = cap
 p.particle_spawn_cube_offset[:] = (2.0, 2.0, 2.0)
 p.particle_spawn_cube_size[:] = size
 rank = ranks // 2
-for mode, name in ((0, "compact storage"),):
+# the loop's exchange schedule: the driver's default (8 planes per exchange, both passes around an exchange split so
+# that it runs beside them — what a real wire wants) and what bench.py's probe picks in loopback, where an
+# exchange is a device copy (3 planes per exchange, in line)
+for mode, name, halo, overlap in ((0, "compact storage, h = 8, split passes", 8, S.OVERLAP_BOTH),
+                                  (0, "compact storage, h = 3, exchanges in line", 3, S.OVERLAP_NONE)):
     with S.SlabDriver(p, rank, ranks, particle_capacity=cap, pressure_iterations=iters, device=0) as drv:
         drv.engine.set_option(E.OPT_PARTICLE_SORT, mode)
+        drv.set_option(S.OPT_HALO_DEPTH, halo)
+        drv.set_option(S.OPT_OVERLAP, overlap)
         drv.attach_loopback(True, True)
         drv.run_init()
         for _ in range(3):
