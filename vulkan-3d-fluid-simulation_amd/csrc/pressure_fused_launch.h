@@ -23,12 +23,15 @@ namespace fluid {
 // Estimate the makespan of every candidate chunk length by dealing the tiles (cost = planes + 2
 // pipeline steps + a fixed start-up) to the CUs in launch order, and take the best.  Host
 // arithmetic, cached per geometry.
-static inline int pick_zchunk(int row_groups, int depth, int cus, int sweeps = 2) {
+// depth2: a second segment of planes cut into chunks of the same length (the EDGES launch of a split pass covers
+// the planes at both faces of a slab: twice the workgroups — modelled as one segment it took chunks of two planes
+// at h = 8, 512 workgroups in two rounds of eight steps where 256 of ten do)
+static inline int pick_zchunk(int row_groups, int depth, int cus, int sweeps = 2, int depth2 = 0) {
     // cached per geometry (a slab loop alternates between a few depths; the model costs ~1 ms)
     static std::map<std::tuple<int, int, int, int>, int> cache;
     static std::mutex cache_mutex;  // contexts of different host threads share this table
     std::lock_guard<std::mutex> lock(cache_mutex);
-    const auto key = std::make_tuple(row_groups, depth, cus, sweeps);
+    const auto key = std::make_tuple(row_groups, depth + 4096 * depth2, cus, sweeps);
     const auto hit = cache.find(key);
     if (hit != cache.end()) return hit->second;
     const double startup = 3.0;
@@ -36,19 +39,21 @@ static inline int pick_zchunk(int row_groups, int depth, int cus, int sweeps = 2
     int best = std::min(depth, 32);
     for (int zc = std::min(depth, row_groups * (depth / 16) >= cus ? 16 : 2); zc <= std::min(depth, 128);
          zc++) {
-        const int nz = (depth + zc - 1) / zc;
         std::vector<double> busy(cus, 0.0);  // min-heap by finish time
         auto cmp = [](double a, double b) { return a > b; };
         std::make_heap(busy.begin(), busy.end(), cmp);
         double makespan = 0.0;
-        for (int z = 0; z < nz; z++) {
-            const int planes = std::min(zc, depth - z * zc);
-            const double cost = planes + 2 * (sweeps - 1) + startup;  // pipeline steps of a T-sweep march
-            for (int y = 0; y < row_groups; y++) {
-                std::pop_heap(busy.begin(), busy.end(), cmp);
-                busy.back() += cost;
-                makespan = std::max(makespan, busy.back());
-                std::push_heap(busy.begin(), busy.end(), cmp);
+        for (int seg = 0; seg < 2; seg++) {
+            const int len = seg == 0 ? depth : depth2;
+            for (int z = 0; z * zc < len; z++) {
+                const int planes = std::min(zc, len - z * zc);
+                const double cost = planes + 2 * (sweeps - 1) + startup;  // pipeline steps of a T-sweep march
+                for (int y = 0; y < row_groups; y++) {
+                    std::pop_heap(busy.begin(), busy.end(), cmp);
+                    busy.back() += cost;
+                    makespan = std::max(makespan, busy.back());
+                    std::push_heap(busy.begin(), busy.end(), cmp);
+                }
             }
         }
         if (makespan < best_cost) {
@@ -261,7 +266,7 @@ static hipError_t launch_keep(hipStream_t s, const uint8_t* mask, const float* r
     const int seg1 = r.hole_lo - r.zout_lo, seg2 = r.zout_hi - r.hole_hi;
     const int depth = std::max(seg1, seg2);
     if (depth <= 0) return hipSuccess;
-    int zchunk = std::min(pick_zchunk(by, depth, cu_count(), T), depth);
+    int zchunk = std::min(pick_zchunk(by, depth, cu_count(), T, std::min(seg1, seg2)), depth);
     // Sparse scene without a box (Z slab: the ghost planes are not covered by the activity map): most
     // workgroups leave at once and the few that work should be short, so that they run side by side.
     if (!box.valid && box.fraction >= 0.f &&
