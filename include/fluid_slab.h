@@ -193,6 +193,22 @@ typedef enum fluid_slab_option {
 } fluid_slab_option;
 int fluid_slab_set_option(fluid_slab* s, int option, int64_t value);
 
+/* Measure the loop's exchange schedules where they run and adopt the fastest: for every halo depth in {8, 6, 3}
+ * the slabs allow (3 + 3 + 2, 3 + 3 or 3 sweeps between two exchanges where the loop applies three per launch) and
+ * every fluid_slab_overlap, one fluid_slab_pressure_step after an untimed one of its own; the times are reduced
+ * with MAX over the ranks, so every rank comes to the same choice and sets FLUID_SLAB_OPT_HALO_DEPTH /
+ * _OVERLAP accordingly.  Collective; overwrites PRESSURES_1 / _2 (call it before the run, or between steps:
+ * 12a / 12b clear them anyway).  Whether hiding an exchange is worth two more launches per pass, and whether
+ * fewer, larger messages beat less recomputation of ghost planes, depends on the link: in a one-GPU rehearsal,
+ * where an exchange is a device copy, three planes in line win; the defaults (8 planes, both passes split) are
+ * what a wire with tens of microseconds per exchange wants.  times_us (optional): 9 entries, [3 * i + overlap]
+ * for the i-th depth of {8, 6, 3}, 0 where not measured.  bench.py --gpus N calls this before its warm-up. */
+typedef struct fluid_slab_tune_result {
+    uint32_t halo_depth, overlap;  /* adopted */
+    uint32_t times_us[9];
+} fluid_slab_tune_result;
+int fluid_slab_tune_exchange(fluid_slab* s, fluid_slab_tune_result* result /* may be NULL */);
+
 typedef enum fluid_slab_stat {
     FLUID_SLAB_STAT_EXCHANGES = 0,        /* plane exchanges issued                                      */
     FLUID_SLAB_STAT_OVERLAPPED = 1,       /* ... of which started beside a split pass                     */

@@ -146,6 +146,50 @@ def test_rccl_communicator_of_one_and_loopback_rehearsal():
             assert_bit_equal(a, b, f"loopback by copies vs by RCCL, overlap {overlap}")
 
 
+def test_tune_exchange_adopts_the_fastest_schedule_and_changes_no_result():
+    """fluid_slab_tune_exchange on an interior rank of an 8-way run (loopback, and through RCCL to itself): every
+    halo depth of 8 / 6 / 3 and every overlap schedule is timed, the fastest one is what the driver uses
+    afterwards, and the loop's iterates are those of the default schedule, bit for bit."""
+    import fluid_amd
+    from fluid_amd import engine as E
+    from fluid_amd import scenes
+    from fluid_amd import slab as S
+    from helpers import assert_bit_equal
+
+    p = fluid_amd.default_params(256, 64, 256, 0)
+    want = None
+    for wire in ("copies", "rccl"):
+        with S.SlabDriver(p, 3, 8, pressure_iterations=33, device=0) as mid:
+            if wire == "copies":
+                mid.attach_loopback(True, True)
+            else:
+                mid.attach_rccl_self(True, True)
+            z0, n = mid.slab
+            assert n == 32
+            mid.upload_image(E.CELL_TYPES, scenes.full_fluid_types((n, 64, 256), z0, 256))
+            mid.engine.upload_image(E.DIVERGENCES, scenes.full_fluid_divergence((n, 64, 256), z_begin=z0))
+            mid.pressure_step()   # the default schedule: 8 planes per exchange, both passes split
+            mid.engine.sync()
+            assert mid.stat(S.STAT_EFFECTIVE_HALO) == 8 and mid.stat(S.STAT_OVERLAPPED) > 0
+            ref = (mid.engine.download_image(E.PRESSURES_1), mid.engine.download_image(E.PRESSURES_2))
+            r = mid.tune_exchange()
+            assert r["halo_depth"] in (8, 6, 3) and r["overlap"] in (0, 1, 2)
+            assert len(r["times_ms"]) == 9 and all(v > 0 for v in r["times_ms"].values())
+            best = min(r["times_ms"], key=r["times_ms"].get)
+            assert best == f"h{r['halo_depth']}_overlap{r['overlap']}"
+            mid.pressure_step()
+            mid.engine.sync()
+            assert mid.stat(S.STAT_EFFECTIVE_HALO) == r["halo_depth"]
+            got = (mid.engine.download_image(E.PRESSURES_1), mid.engine.download_image(E.PRESSURES_2))
+            for a, b in zip(ref, got):
+                assert np.isfinite(a).all()
+                assert_bit_equal(a, b, f"default schedule vs the tuned one ({best}), {wire}")
+            if want is None:
+                want = ref
+            for a, b in zip(want, ref):
+                assert_bit_equal(a, b, "loopback by copies vs by RCCL")
+
+
 def test_single_rank_slab_bench_path_runs():
     """world_size 1 through the same driver + benchmark code the multi-GPU bench uses (RCCL group
     of one)."""

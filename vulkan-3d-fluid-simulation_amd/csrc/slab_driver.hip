@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1294,6 +1295,58 @@ int fluid_slab_pressure_step(fluid_slab* s) {
     if (!s) return FLUID_ERR_INVALID_ARG;
     TRY(need_transport(s));
     return pressure_step(s);
+}
+
+int fluid_slab_tune_exchange(fluid_slab* s, fluid_slab_tune_result* result) {
+    if (!s) return FLUID_ERR_INVALID_ARG;
+    TRY(need_transport(s));
+    fluid_slab_tune_result r{};
+    r.halo_depth = s->halo_depth;
+    r.overlap = (uint32_t)s->overlap;
+    if (s->world > 1 && s->tr) {
+        uint32_t max_sweeps = 1, max_halo = 1;
+        BE(loop_limits(&max_sweeps, &max_halo));
+        const uint32_t depths[3] = {8, 6, 3};
+        const uint32_t old_h = s->halo_depth;
+        const int old_overlap = s->overlap;
+        uint32_t best_t = 0xFFFFFFFFu;
+        for (int i = 0; i < 3; i++) {
+            const uint32_t h = depths[i];
+            // (a depth the slabs or the loop cannot use would only repeat another one's measurement)
+            if (h > std::min(max_halo, s->thinnest)) continue;
+            if (i > 0 && max_sweeps < 3 && h % 2) continue;
+            for (int mode = FLUID_SLAB_OVERLAP_NONE; mode <= FLUID_SLAB_OVERLAP_BOTH; mode++) {
+                s->halo_depth = h;
+                s->overlap = mode;
+                int rc = pressure_step(s);  // untimed: the first loop of a schedule builds its plans
+                if (rc == FLUID_OK) rc = s->from_backend(s->be->sync());
+                uint32_t zero = 0;
+                if (rc == FLUID_OK) rc = reduce_max(s, &zero, 1);  // everybody starts the timed loop together
+                const auto t0 = std::chrono::steady_clock::now();
+                if (rc == FLUID_OK) rc = pressure_step(s);
+                if (rc == FLUID_OK) rc = s->from_backend(s->be->sync());
+                if (rc) {
+                    s->halo_depth = old_h;
+                    s->overlap = old_overlap;
+                    return rc;
+                }
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                uint32_t t = (uint32_t)std::min(us, 4.0e9);
+                TRY(reduce_max(s, &t, 1));
+                r.times_us[3 * i + mode] = t;
+                if (t < best_t) {
+                    best_t = t;
+                    r.halo_depth = h;
+                    r.overlap = (uint32_t)mode;
+                }
+            }
+        }
+        s->halo_depth = r.halo_depth;
+        s->overlap = (int)r.overlap;
+        s->stats[FLUID_SLAB_STAT_EFFECTIVE_HALO] = 0;
+    }
+    if (result) *result = r;
+    return FLUID_OK;
 }
 
 int fluid_slab_solve(fluid_slab* s, uint32_t iterations) {

@@ -107,6 +107,14 @@ int main(int argc, char** argv) {
         const double ms =
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rank == 0) std::printf("frame %d: %.3f ms\n", f, ms);
+        if (f == 0 && world > 1) {
+            // the loop's exchange schedule, measured on this machine's links with the scene's water in place
+            // (PRESSURES_1 / _2 are overwritten: the next frame clears them anyway; no result changes)
+            fluid_slab_tune_result tr{};
+            if ((rc = fluid_slab_tune_exchange(s, &tr))) return die(s, "fluid_slab_tune_exchange", rc);
+            if (rank == 0)
+                std::printf("exchange schedule: %u planes per exchange, overlap mode %u\n", tr.halo_depth, tr.overlap);
+        }
     }
     if (!out_dir.empty()) {
         const int imgs[] = {FLUID_IMG_VELOCITIES_1, FLUID_IMG_CELL_TYPES, FLUID_IMG_PRESSURES_1,

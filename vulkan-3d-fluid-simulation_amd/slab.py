@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "fluid_slab_attach_rccl", "fluid_slab_attach_transport", "fluid_slab_attach_loopback",
     "fluid_slab_attach_rccl_self",
     "fluid_slab_run_init", "fluid_slab_run_step", "fluid_slab_pressure_step", "fluid_slab_solve",
-    "fluid_slab_exchange_image", "fluid_slab_set_option", "fluid_slab_get_stat",
+    "fluid_slab_exchange_image", "fluid_slab_set_option", "fluid_slab_get_stat", "fluid_slab_tune_exchange",
 ]
 
 
@@ -51,6 +51,10 @@ class SlabCreateInfo(C.Structure):
         ("pressure_iterations", C.c_uint32), ("halo_depth", C.c_uint32), ("overlap", C.c_int32),
         ("section_list", C.c_uint32), ("diffuse_mode", C.c_int32), ("sampler_halo", C.c_uint32),
     ]
+
+
+class TuneResult(C.Structure):
+    _fields_ = [("halo_depth", C.c_uint32), ("overlap", C.c_uint32), ("times_us", C.c_uint32 * 9)]
 
 
 class Xfer(C.Structure):
@@ -134,6 +138,7 @@ def _lib():
             "fluid_slab_run_init": (C.c_int, [vp]),
             "fluid_slab_run_step": (C.c_int, [vp]),
             "fluid_slab_pressure_step": (C.c_int, [vp]),
+            "fluid_slab_tune_exchange": (C.c_int, [vp, C.c_void_p]),
             "fluid_slab_solve": (C.c_int, [vp, _u32]),
             "fluid_slab_exchange_image": (C.c_int, [vp, C.c_int, _u32]),
             "fluid_slab_set_option": (C.c_int, [vp, C.c_int, C.c_int64]),
@@ -514,6 +519,15 @@ class SlabDriver:
     def set_option(self, option: int, value: int):
         self._check(self._lib.fluid_slab_set_option(self._h, option, value))
 
+    def tune_exchange(self) -> dict:
+        """fluid_slab_tune_exchange: the loop's exchange schedules measured where they run, the fastest adopted
+        (collective).  Returns the choice and the times in ms keyed "h<depth>_overlap<mode>"."""
+        r = TuneResult()
+        self._check(self._lib.fluid_slab_tune_exchange(self._h, C.byref(r)))
+        times = {f"h{h}_overlap{m}": r.times_us[3 * i + m] / 1e3
+                 for i, h in enumerate((8, 6, 3)) for m in range(3) if r.times_us[3 * i + m]}
+        return {"halo_depth": int(r.halo_depth), "overlap": int(r.overlap), "times_ms": times}
+
     def stat(self, which: int) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.fluid_slab_get_stat(self._h, which, C.byref(v)))
@@ -658,9 +672,16 @@ class SlabDriver:
             return {"used": mode, "probed": False, "halo_depth": self.stat(STAT_EFFECTIVE_HALO)}
         if self.world == 1 or not dist.is_initialized():
             return {"used": OVERLAP_NONE, "probed": False, "halo_depth": self.stat(STAT_EFFECTIVE_HALO)}
-        thinnest = self.params.size[2] // self.world
-        depths = [int(env_h)] if env_h is not None else sorted(
-            {h for h in (8, 6, 3) if h <= min(thinnest, 8)} or {min(thinnest, 8)}, reverse=True)
+        if env_h is None:
+            # the driver's own tuner (fluid_slab_tune_exchange): depths 8 / 6 / 3 x the three schedules
+            r = self.tune_exchange()
+            t = r["times_ms"]
+            key = lambda m: t.get(f"h{r['halo_depth']}_overlap{m}")
+            return {"used": r["overlap"], "probed": True, "halo_depth": r["halo_depth"],
+                    "step_ms_inline": key(OVERLAP_NONE), "step_ms_overlap_before": key(OVERLAP_BEFORE),
+                    "step_ms_overlapped": key(OVERLAP_BOTH),
+                    "step_ms_by_halo_depth_and_schedule": {k: round(v, 4) for k, v in t.items()}}
+        depths = [int(env_h)]  # a forced depth: its three schedules, timed here
         times = {}
         for h in depths:
             self.set_option(OPT_HALO_DEPTH, h)
