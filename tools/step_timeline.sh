@@ -1,9 +1,11 @@
 # dev: kernel timeline of one sparse (dam-break) step: start, duration and the gap to the previous kernel's end
 #   bash tools/step_timeline.sh [out=tl] [grid=512]          DENSE=1: the full tank (tools/full_fluid_step.py) instead;
-#   SLAB=1: the middle rank of its 8-way split (tools/slab_dense_rank_step.py)
+#   SLAB=1: the middle rank of its 8-way split (tools/slab_dense_rank_step.py); SCRIPT=tools/x.py: that program
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-tl}; N=${2:-512}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ -n "$SLAB" ]; then
+if [ -n "$SCRIPT" ]; then
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o tl -- python3 $ROOT/$SCRIPT $N > $OUT/run.log 2>&1
+elif [ -n "$SLAB" ]; then
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o tl -- python3 $ROOT/tools/slab_dense_rank_step.py $N 8 > $OUT/run.log 2>&1
 elif [ -n "$DENSE" ]; then
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o tl -- python3 $ROOT/tools/full_fluid_step.py $N 200 > $OUT/run.log 2>&1
